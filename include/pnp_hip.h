@@ -1,0 +1,127 @@
+/* pnp_hip.h - C ABI of libpnp_hip.so, the MI355X (gfx950) batched PnP pose solver.
+ *
+ * The reference (Benson516/pnp_solver_test) is pure Python and has no FFI of its own; the
+ * boundary this library sits behind is the Python method PNP_SOLVER.solve_pnp
+ * (scripts/PNP_SOLVER_LIB.py:144-203) and the per-pattern solvers it dispatches to.  Each
+ * entry point below names the reference function whose results it reproduces.
+ *
+ * Conventions shared by all entry points
+ *   - Arrays are dense, row-major, caller-allocated.  uv is (B,N,2) float32 pixel
+ *     coordinates; xyz is the 3-D pattern, either one (N,3) float32 array shared by all
+ *     problems (xyz_problem_stride == 0) or one per problem (xyz_problem_stride = number of
+ *     floats between consecutive problems, normally 3*N).
+ *   - K is the 3x3 camera matrix in float64, row-major (np_K_camera_est of the reference
+ *     constructor, PNP_SOLVER_LIB.py:10-14).  It is inverted in float64 on the host, as the
+ *     reference does with numpy.linalg.inv (:2811, :3097).
+ *   - Arithmetic is float64 on float32 inputs; outputs are rounded to float32 once.
+ *   - ptr_kind: PNP_PTR_HOST = every array pointer is host memory (the library stages
+ *     through device buffers and synchronises before returning); PNP_PTR_DEVICE = every
+ *     array pointer is device memory on the current HIP device (the call only enqueues work
+ *     on hip_stream and returns; nothing is allocated).
+ *   - hip_stream: a hipStream_t cast to void*, or NULL for the default stream.
+ *   - Return value: 0 on success, a negative PNP_E_* code otherwise; pnp_last_error() then
+ *     returns a thread-local, human-readable description.  Numerically degenerate problems
+ *     are not errors: as in the reference they produce NaN/inf in their own outputs.
+ *   - Output pointers documented as optional may be NULL.
+ *   - Thread safety: calls are independent as long as they do not share output buffers;
+ *     host-pointer calls on one device serialise on that device's staging buffers.
+ */
+#ifndef PNP_HIP_H
+#define PNP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNP_PTR_HOST 0
+#define PNP_PTR_DEVICE 1
+
+#define PNP_OK 0
+#define PNP_E_ARG (-1)     /* bad argument (NULL pointer, N out of range, ...) */
+#define PNP_E_HIP (-2)     /* a HIP runtime call failed                         */
+#define PNP_E_NODEVICE (-3)
+
+/* Tunables of the quaternion information-filter solver; the defaults are the constants
+ * hard-coded in solve_pnp_QEIF_single_pattern (PNP_SOLVER_LIB.py:2791-2794, :2836,
+ * :2845-2846, :2857, :2863, :2952). */
+typedef struct pnp_qeif_params {
+    double q_inv;     /* 1/Q with Q = 3^2/f^2, f = 225.68 (not taken from K)  -> 5659.05 */
+    double r_quat;    /* process noise added to the quaternion block each step -> 0.1   */
+    double r_delta;   /* process noise added to delta_1, delta_2               -> 0.01  */
+    double omega0;    /* initial information matrix = omega0 * I               -> 1e-5  */
+    int32_t max_it;   /* iteration cap                                         -> 14    */
+    double rel_tol;   /* stop when |res - res_old| / res_old < rel_tol         -> 1e-2  */
+    double res_old0;  /* initial res_old                                       -> 1e-7  */
+} pnp_qeif_params;
+
+/* Fills *p with the reference defaults listed above. */
+void pnp_qeif_default_params(pnp_qeif_params *p);
+
+/* Number of HIP devices visible to this process (0 if none, negative on error). */
+int pnp_device_count(void);
+
+/* Makes `device` the calling thread's current HIP device and prepares its context.
+ * Optional: every entry point initialises the current device on first use. */
+int pnp_init(int device);
+
+/* Replaces solve_pnp_QEIF_single_pattern (PNP_SOLVER_LIB.py:2771-3025) with its model
+ * QEKF_get_hx_H (:3902-3983) and reconstruction QEKF_reconstruct_R_t_m1 (:3542-3609),
+ * for B independent problems of N points each.
+ *   R_out   (B,9)  rotation, row-major                      required
+ *   t_out   (B,3)  translation; t_out[2] is t3_est          required
+ *   res_out (B)    res_norm at the last linearisation point optional
+ *   iters_out (B)  iterations executed (1..max_it)          optional
+ *   rpy_out (B,3)  roll, yaw, pitch in degrees, in the order of the reference's return
+ *                  tuple (get_Euler_from_rotation_matrix, :4474-4517)   optional
+ *   p: NULL = reference defaults. */
+int pnp_qeif_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_stride,
+                       const double K[9], int64_t B, int32_t N, const pnp_qeif_params *p,
+                       float *R_out, float *t_out, float *res_out, int32_t *iters_out,
+                       float *rpy_out, int32_t ptr_kind, void *hip_stream);
+
+/* Replaces solve_pnp_single_pattern (PNP_SOLVER_LIB.py:205-430): num_it rounds (reference:
+ * 3) of the linear system of get_Delta_A_all / get_B_all (:3064-3111), the closed-form
+ * reconstruct_R_t_block_reconstruction (:4158-4364) and update_phi_3_est_m2 (:4002-4017).
+ * res_out is the residual norm of the last round (:372-380).  Outputs as above. */
+int pnp_dlt_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_stride,
+                      const double K[9], int64_t B, int32_t N, int32_t num_it, float *R_out,
+                      float *t_out, float *res_out, float *rpy_out, int32_t ptr_kind,
+                      void *hip_stream);
+
+/* Replaces get_Euler_from_rotation_matrix(R, is_degree=True) (PNP_SOLVER_LIB.py:4474-4517)
+ * for B matrices: R (B,9) -> rpy (B,3) = roll, yaw, pitch in degrees. */
+int pnp_euler_deg_f32(const float *R, int64_t B, float *rpy, int32_t ptr_kind, void *hip_stream);
+
+/* Replaces the pattern loop of solve_pnp (PNP_SOLVER_LIB.py:166-199): runs the QEIF solver
+ * against n_patterns shared patterns, xyz (n_patterns,N,3), and keeps for every problem the
+ * first pattern with the strictly smallest res_norm.  pattern_id_out (B) int32 is optional;
+ * the other outputs are those of pnp_qeif_batch_f32. */
+int pnp_qeif_multi_batch_f32(const float *uv, const float *xyz, int32_t n_patterns,
+                             const double K[9], int64_t B, int32_t N, const pnp_qeif_params *p,
+                             float *R_out, float *t_out, float *res_out, int32_t *iters_out,
+                             float *rpy_out, int32_t *pattern_id_out, int32_t ptr_kind,
+                             void *hip_stream);
+
+/* How many lanes of a wavefront cooperate on one problem: 1, 2, 4, 8, 16, 32 or 64
+ * (64 = one wavefront per problem); 0 restores the automatic choice from (B, N).
+ * Process-wide; meant for tuning and tests.  No reference counterpart. */
+int pnp_set_lanes_per_problem(int32_t lanes);
+
+/* The value the next launch would use for (B, N). */
+int pnp_get_lanes_per_problem(int64_t B, int32_t N, int64_t xyz_problem_stride);
+
+/* Largest N accepted by the solvers. */
+int pnp_max_points(void);
+
+/* Thread-local description of the last failure in the calling thread ("" if none). */
+const char *pnp_last_error(void);
+
+/* Library version string. */
+const char *pnp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNP_HIP_H */

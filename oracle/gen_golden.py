@@ -1,0 +1,319 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Run in the build container only (the reference tree is not present on the GPU box):
+
+    python oracle/gen_golden.py [--ref /root/reference/scripts] [--out tests/golden]
+
+The reference modules are imported from where they lie (nothing is copied; bytecode
+writing is disabled so the read-only tree is left untouched).  `cv2` is absent in this
+image and only needed by the reference's drawing helpers, so an empty stand-in module is
+registered for the import of its evaluation toolbox; no cv2 function is ever called.
+
+Each .npz holds inputs and the reference's outputs for one family of cases.  2-D inputs
+are float32-representable by construction (integer pixels, or rounded to float32 before
+being handed to the reference as float64), so the float32 device path sees the same
+numbers.  Seeds and sizes are fixed below; re-running reproduces the files bit for bit
+on the same NumPy/LAPACK build.
+"""
+import argparse
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+
+F_CAMERA = 225.68717584155982
+K = np.array([[F_CAMERA, 0.0, 160.0], [0.0, F_CAMERA, 120.0], [0.0, 0.0, 1.0]])
+LM6 = ['eye_l_96', 'eye_r_97', 'mouse_l_76', 'mouse_r_82', 'nose_t_54', 'chin_t_16']
+
+
+def load_reference(ref_dir):
+    sys.path.insert(0, ref_dir)
+    sys.modules.setdefault('cv2', types.ModuleType('cv2'))
+    import PNP_SOLVER_LIB as PNPS
+    import TEST_TOOLBOX as TTBX
+    return PNPS, TTBX
+
+
+class IterCounter:
+    """Counts calls of a bound method; the QEIF loop evaluates its model once per
+    iteration, so calls == iterations."""
+
+    def __init__(self, solver, name):
+        self.n = 0
+        self._orig = getattr(solver, name)
+        setattr(solver, name, self)
+
+    def __call__(self, *a, **kw):
+        self.n += 1
+        return self._orig(*a, **kw)
+
+
+def draw_stress_pose(rng):
+    """random_stress_test.py:245-258, same draw order."""
+    ang = 45.0
+    roll = rng.uniform(-ang, ang, None)
+    pitch = rng.uniform(-ang, ang, None)
+    yaw = rng.uniform(-ang, ang, None)
+    depth = rng.uniform(20, 225, None) / 100.0
+    fov_x = rng.uniform(-45.0, 45.0, None)
+    fov_y = rng.uniform(-45.0, 45.0, None)
+    t = np.zeros((3, 1))
+    t[0, 0] = depth * np.tan(np.deg2rad(fov_x))
+    t[1, 0] = depth * np.tan(np.deg2rad(fov_y))
+    t[2, 0] = depth
+    return roll, pitch, yaw, t
+
+
+def dict_to_uv(d, keys):
+    return np.array([[d[k][0, 0], d[k][1, 0]] for k in keys])
+
+
+def uv_to_dict(uv, keys):
+    return {k: np.array([[uv[i, 0]], [uv[i, 1]], [1.0]]) for i, k in enumerate(keys)}
+
+
+def pack(results):
+    """list of reference 7-tuples -> dict of stacked arrays."""
+    return dict(
+        R=np.array([r[0] for r in results]),
+        t=np.array([r[1][:, 0] for r in results]),
+        t3=np.array([r[2] for r in results]),
+        roll=np.array([r[3] for r in results]),
+        yaw=np.array([r[4] for r in results]),
+        pitch=np.array([r[5] for r in results]),
+        res_norm=np.array([r[6] for r in results]),
+    )
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--ref', default='/root/reference/scripts')
+    ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
+    ap.add_argument('--n-stress', type=int, default=10000)
+    ap.add_argument('--only', default='', help='comma-separated section numbers (1-8); default all')
+    args = ap.parse_args()
+    out_dir = os.path.abspath(args.out)
+    os.makedirs(out_dir, exist_ok=True)
+    PNPS, TTBX = load_reference(args.ref)
+    t_start = time.time()
+
+    alex = TTBX.get_golden_pattern('Alexander')
+    holly = TTBX.get_golden_pattern('Holly')
+    keys15 = list(alex.keys())
+    gt = PNPS.PNP_SOLVER(K, [alex], pattern_scale_list=[1.0], verbose=False)
+    est = PNPS.PNP_SOLVER(K, [alex], pattern_scale_list=[1.0], verbose=False)
+    counter = IterCounter(est, 'QEKF_get_hx_H')
+
+    only = set(int(v) for v in args.only.split(',') if v)
+
+    def want(section):
+        return not only or section in only
+
+    def save(name, **arrs):
+        path = os.path.join(out_dir, name)
+        np.savez_compressed(path, **arrs)
+        print('wrote %s (%.1f KB)  t=%.0fs' % (name, os.path.getsize(path) / 1024.0, time.time() - t_start))
+
+    # ---- 1. known-answer cases -------------------------------------------------
+    if want(1):
+        R_known = gt.get_rotation_matrix_from_Euler(15.0, 45.0, -15.0, is_degree=True)
+        t_known = np.array([[0.35], [0.35], [0.5]])          # random_stress_test.py:260-270
+        img = gt.perspective_projection_golden_landmarks(R_known, t_known, is_quantized=True)
+        counter.n = 0
+        known = est.solve_pnp(img)
+        known_iters = counter.n
+        # Euler helpers: round trip of PNP_SOLVER_LIB.py:4727-4732 plus a spread of angles and
+        # two gimbal-locked matrices
+        e_in, e_R, e_out = [], [], []
+        rng = np.random.default_rng(7)
+        angles = [(45.0, 40.0, -15.0), (0.0, 0.0, 0.0), (10.0, 35.0, -25.0), (0.0, 0.0, 90.0),
+                  (30.0, -20.0, -90.0), (170.0, 100.0, 60.0)]
+        angles += [tuple(rng.uniform(-180, 180, 3)) for _ in range(58)]
+        for (ro, ya, pi) in angles:
+            Rm = gt.get_rotation_matrix_from_Euler(ro, ya, pi, is_degree=True)
+            e_in.append([ro, ya, pi])
+            e_R.append(Rm)
+            e_out.append(gt.get_Euler_from_rotation_matrix(Rm, verbose=False, is_degree=True))
+        save('known_cases.npz',
+             uv15=dict_to_uv(img, keys15), keys15=np.array(keys15), lm6=np.array(LM6),
+             R_gt=R_known, t_gt=t_known[:, 0], iters=np.int32(known_iters),
+             euler_in=np.array(e_in), euler_R=np.array(e_R), euler_out=np.array(e_out, dtype=np.float64),
+             **{k: v[0] for k, v in pack([known]).items()})
+
+    # ---- 2. random-stress run, QEIF through solve_pnp (15-key dict, 6 used) ------
+    if want(2):
+        n = args.n_stress
+        rng = np.random.default_rng(42)
+        draws = np.zeros((n, 3))
+        t_gt = np.zeros((n, 3))
+        uv15 = np.zeros((n, 15, 2))
+        iters = np.zeros(n, dtype=np.int32)
+        passed = np.zeros((n, 4), dtype=bool)
+        res = []
+        for i in range(n):
+            roll, pitch, yaw, t = draw_stress_pose(rng)
+            R = gt.get_rotation_matrix_from_Euler(roll, yaw, pitch, is_degree=True)
+            img = gt.perspective_projection_golden_landmarks(R, t, is_quantized=True)
+            counter.n = 0
+            out = est.solve_pnp(img)
+            iters[i] = counter.n
+            res.append(out)
+            draws[i] = [roll, pitch, yaw]
+            t_gt[i] = t[:, 0]
+            uv15[i] = dict_to_uv(img, keys15)
+            flags, _ = TTBX.check_if_the_sample_passed(           # random_stress_test.py:374-377
+                (out[2] * 100.0, out[3], out[5], out[4]),
+                (t[2, 0] * 100.0, roll, pitch, yaw), (10.0, 10.0, 10.0, 10.0))
+            passed[i] = flags
+        save('stress_qeif_n6.npz', seed=np.int64(42), roll_gt=draws[:, 0], pitch_gt=draws[:, 1],
+             yaw_gt=draws[:, 2], t_gt=t_gt, uv15=uv15.astype(np.float32), keys15=np.array(keys15),
+             lm6=np.array(LM6), iters=iters, passed=passed, **pack(res))
+
+    # ---- 3. QEIF on exact (unquantised) projections rounded to float32 -----------
+    if want(3):
+        n = 2048
+        rng = np.random.default_rng(43)
+        uv6 = np.zeros((n, 6, 2), dtype=np.float32)
+        iters = np.zeros(n, dtype=np.int32)
+        res = []
+        for i in range(n):
+            roll, pitch, yaw, t = draw_stress_pose(rng)
+            R = gt.get_rotation_matrix_from_Euler(roll, yaw, pitch, is_degree=True)
+            img = gt.perspective_projection_golden_landmarks(R, t, is_quantized=False)
+            uv6[i] = dict_to_uv(img, LM6).astype(np.float32)
+            counter.n = 0
+            res.append(est.solve_pnp(uv_to_dict(uv6[i].astype(np.float64), LM6)))
+            iters[i] = counter.n
+        save('qeif_n6_exact.npz', seed=np.int64(43), uv=uv6, iters=iters, **pack(res))
+
+    # ---- 4. iterated DLT, 6 and 15 points ----------------------------------------
+    if want(4):
+        for tag, keys, count, seed in (('dlt_n6', LM6, 2048, 44), ('dlt_n15', keys15, 1024, 45)):
+            rng = np.random.default_rng(seed)
+            uv = np.zeros((count, len(keys), 2), dtype=np.float32)
+            on_axis = np.zeros(count, dtype=bool)
+            raised = np.zeros(count, dtype=bool)
+            res = []
+            pat = est.np_point_3d_pretransfer_dict_list[0]
+            for i in range(count):
+                roll, pitch, yaw, t = draw_stress_pose(rng)
+                if i % 4 == 3:                     # every 4th case on the optical axis, where
+                    t[0, 0] = t[1, 0] = 0.0        # this method is accurate
+                    on_axis[i] = True
+                R = gt.get_rotation_matrix_from_Euler(roll, yaw, pitch, is_degree=True)
+                img = gt.perspective_projection_golden_landmarks(R, t, is_quantized=True)
+                uv[i] = dict_to_uv(img, keys).astype(np.float32)
+                try:
+                    res.append(est.solve_pnp_single_pattern(uv_to_dict(uv[i].astype(np.float64), keys), pat))
+                except np.linalg.LinAlgError:
+                    # the reference's inspection SVD (:256-258) raises once an earlier
+                    # iteration has produced NaN; recorded as a NaN result
+                    raised[i] = True
+                    nan = np.float64('nan')
+                    res.append((np.full((3, 3), nan), np.full((3, 1), nan), nan, nan, nan, nan, nan))
+            save(tag + '.npz', seed=np.int64(seed), uv=uv, keys=np.array(keys), on_axis=on_axis,
+                 raised=raised, **pack(res))
+
+    # ---- 5. QEIF with the synthetic 68-point pattern -------------------------------
+    if want(5):
+        n = 512
+        P68 = np.random.default_rng(0).uniform([-0.07, -0.05, -0.04], [0.07, 0.12, 0.02], (68, 3))
+        keys68 = ['p%02d' % i for i in range(68)]
+        pat68 = {k: P68[i].tolist() for i, k in enumerate(keys68)}
+        gt68 = PNPS.PNP_SOLVER(K, [pat68], verbose=False)
+        est68 = PNPS.PNP_SOLVER(K, [pat68], verbose=False)
+        c68 = IterCounter(est68, 'QEKF_get_hx_H')
+        rng = np.random.default_rng(46)
+        uv = np.zeros((n, 68, 2), dtype=np.float32)
+        iters = np.zeros(n, dtype=np.int32)
+        res = []
+        for i in range(n):
+            roll, pitch, yaw, t = draw_stress_pose(rng)
+            R = gt68.get_rotation_matrix_from_Euler(roll, yaw, pitch, is_degree=True)
+            img = gt68.perspective_projection_golden_landmarks(R, t, is_quantized=True)
+            uv[i] = dict_to_uv(img, keys68).astype(np.float32)
+            c68.n = 0
+            res.append(est68.solve_pnp_QEIF_single_pattern(
+                uv_to_dict(uv[i].astype(np.float64), keys68),
+                est68.np_point_3d_pretransfer_dict_list[0], LM_key_list=None))
+            iters[i] = c68.n
+        save('qeif_n68.npz', seed=np.int64(46), xyz=P68, uv=uv, iters=iters, **pack(res))
+
+    # ---- 6. two golden patterns, min-residual selection -----------------------------
+    if want(6):
+        n = 512
+        est2 = PNPS.PNP_SOLVER(K, [alex, holly], pattern_scale_list=[1.0, 1.0], verbose=False)
+        gt2 = PNPS.PNP_SOLVER(K, [alex, holly], pattern_scale_list=[1.0, 1.0], verbose=False)
+        rng = np.random.default_rng(47)
+        uv = np.zeros((n, 6, 2), dtype=np.float32)
+        best = np.zeros(n, dtype=np.int32)
+        res = []
+        for i in range(n):
+            roll, pitch, yaw, t = draw_stress_pose(rng)
+            R = gt2.get_rotation_matrix_from_Euler(roll, yaw, pitch, is_degree=True)
+            gt2.set_golden_pattern_id(i % 2)
+            img = gt2.perspective_projection_golden_landmarks(R, t, is_quantized=True)
+            uv[i] = dict_to_uv(img, LM6).astype(np.float32)
+            res.append(est2.solve_pnp(uv_to_dict(uv[i].astype(np.float64), LM6)))
+            best[i] = est2.current_golden_pattern_id
+        save('multi_pattern.npz', seed=np.int64(47), uv=uv,
+             xyz=np.array([[alex[k] for k in LM6], [holly[k] for k in LM6]]),
+             true_pattern=(np.arange(n) % 2).astype(np.int32), pattern_id=best, **pack(res))
+
+    # ---- 7. the 12-state Levenberg-Marquardt solver, 6 and 15 points ------------------
+    if want(7):
+        for tag, keys, count, seed in (('lm12_n6', LM6, 256, 48), ('lm12_n15', keys15, 256, 49)):
+            rng = np.random.default_rng(seed)
+            sub = {k: alex[k] for k in keys}
+            est_lm = PNPS.PNP_SOLVER(K, [sub], verbose=False)
+            uv = np.zeros((count, len(keys), 2), dtype=np.float32)
+            res = []
+            for i in range(count):
+                roll, pitch, yaw, t = draw_stress_pose(rng)
+                R = gt.get_rotation_matrix_from_Euler(roll, yaw, pitch, is_degree=True)
+                img = gt.perspective_projection_golden_landmarks(R, t, is_quantized=True)
+                uv[i] = dict_to_uv(img, keys).astype(np.float32)
+                res.append(est_lm.solve_pnp_LM_single_pattern(
+                    uv_to_dict(uv[i].astype(np.float64), keys), est_lm.np_point_3d_pretransfer_dict_list[0]))
+            save(tag + '.npz', seed=np.int64(seed), uv=uv, keys=np.array(keys), **pack(res))
+
+    # ---- 8. landmark-noise sweep on a reduced grid (LM_noise_test.py:141-175, :253-360)
+    if want(8):
+        n_noise_full, n_noise = 2000, 200
+        rng = np.random.default_rng(42)
+        noise_full = rng.multivariate_normal(np.zeros((2,)), np.eye(2), (n_noise_full, 15))
+        noise = noise_full[:n_noise]
+        yaw_list = np.array([0.0, 45.0, 90.0 * 13 / 14])
+        sigma_list = np.array([0.0, 5.0 * 4 / 9, 5.0])
+        q = 1.0 / 112.0 * 30.0
+        yaw_est = np.zeros((len(yaw_list), len(sigma_list), n_noise))
+        uv_clean = np.zeros((len(yaw_list), 15, 2))
+        for yi, yaw_i in enumerate(yaw_list):
+            R = gt.get_rotation_matrix_from_Euler(0.0, yaw_i, 0.0, is_degree=True)
+            t = np.array([0.0, 0.0, 1.0]).reshape((3, 1))
+            lm = gt.perspective_projection_golden_landmarks(R, t, is_quantized=True, quantize_q=q,
+                                                            is_returning_homogeneous_vec=False)
+            uv_clean[yi] = np.array([lm[k] for k in keys15])
+            for si, sigma in enumerate(sigma_list):
+                s_glob = sigma / 112.0 * 30.0
+                for ni in range(n_noise):
+                    # float32-representable inputs (the device path reads float32)
+                    pts = (uv_clean[yi] + s_glob * noise[ni]).astype(np.float32).astype(np.float64)
+                    out = est.solve_pnp(uv_to_dict(pts, keys15))
+                    yaw_est[yi, si, ni] = out[4]
+        err = yaw_est - yaw_list[:, None, None]
+        save('lm_noise_small.npz', seed=np.int64(42), noise=noise, noise_checksum=np.float64(noise_full.sum()),
+             yaw_list=yaw_list, sigma_list=sigma_list, quantize_q=np.float64(q), uv_clean=uv_clean,
+             yaw_est=yaw_est, mesh_mean=err.mean(axis=2), mesh_std=err.std(axis=2),
+             mesh_mae=np.abs(err).mean(axis=2))
+
+    print('done in %.0f s; numpy %s' % (time.time() - t_start, np.__version__))
+
+
+if __name__ == '__main__':
+    main()

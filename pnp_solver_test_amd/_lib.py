@@ -1,0 +1,98 @@
+"""ctypes binding of libpnp_hip.so (C ABI declared in include/pnp_hip.h).
+
+The library is built in-tree by pnp_solver_test_amd/csrc/Makefile.  There is no CPU
+fallback: if the shared object is missing or cannot be loaded, importing the solver fails
+with an explicit error.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpnp_hip.so")
+
+PTR_HOST = 0
+PTR_DEVICE = 1
+
+#: every symbol include/pnp_hip.h declares
+EXPORTS = (
+    "pnp_qeif_default_params", "pnp_device_count", "pnp_init", "pnp_qeif_batch_f32",
+    "pnp_dlt_batch_f32", "pnp_euler_deg_f32", "pnp_qeif_multi_batch_f32",
+    "pnp_set_lanes_per_problem", "pnp_get_lanes_per_problem", "pnp_max_points",
+    "pnp_last_error", "pnp_version",
+)
+
+
+class QeifParams(ctypes.Structure):
+    """Mirror of `pnp_qeif_params`."""
+    _fields_ = [("q_inv", ctypes.c_double), ("r_quat", ctypes.c_double),
+                ("r_delta", ctypes.c_double), ("omega0", ctypes.c_double),
+                ("max_it", ctypes.c_int32), ("rel_tol", ctypes.c_double),
+                ("res_old0", ctypes.c_double)]
+
+
+class PnpError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+
+_lib = None
+
+
+def load():
+    """Load libpnp_hip.so once and declare the argument types of its entry points."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s not found: build it with `make -C pnp_solver_test_amd/csrc` (or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    pp = ctypes.POINTER(QeifParams)
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.pnp_qeif_default_params.argtypes = [pp]
+    lib.pnp_qeif_default_params.restype = None
+    lib.pnp_device_count.argtypes = []
+    lib.pnp_device_count.restype = ctypes.c_int
+    lib.pnp_init.argtypes = [ctypes.c_int]
+    lib.pnp_init.restype = ctypes.c_int
+    lib.pnp_qeif_batch_f32.argtypes = [vp, vp, i64, dp, i64, i32, pp, vp, vp, vp, vp, vp, i32, vp]
+    lib.pnp_qeif_batch_f32.restype = ctypes.c_int
+    lib.pnp_dlt_batch_f32.argtypes = [vp, vp, i64, dp, i64, i32, i32, vp, vp, vp, vp, i32, vp]
+    lib.pnp_dlt_batch_f32.restype = ctypes.c_int
+    lib.pnp_euler_deg_f32.argtypes = [vp, i64, vp, i32, vp]
+    lib.pnp_euler_deg_f32.restype = ctypes.c_int
+    lib.pnp_qeif_multi_batch_f32.argtypes = [vp, vp, i32, dp, i64, i32, pp, vp, vp, vp, vp, vp, vp, i32, vp]
+    lib.pnp_qeif_multi_batch_f32.restype = ctypes.c_int
+    lib.pnp_set_lanes_per_problem.argtypes = [i32]
+    lib.pnp_set_lanes_per_problem.restype = ctypes.c_int
+    lib.pnp_get_lanes_per_problem.argtypes = [i64, i32, i64]
+    lib.pnp_get_lanes_per_problem.restype = ctypes.c_int
+    lib.pnp_max_points.argtypes = []
+    lib.pnp_max_points.restype = ctypes.c_int
+    lib.pnp_last_error.argtypes = []
+    lib.pnp_last_error.restype = ctypes.c_char_p
+    lib.pnp_version.argtypes = []
+    lib.pnp_version.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc < 0:
+        raise PnpError("libpnp_hip: %s (code %d)" % (load().pnp_last_error().decode(), rc))
+
+
+def default_params() -> QeifParams:
+    p = QeifParams()
+    load().pnp_qeif_default_params(ctypes.byref(p))
+    return p
+
+
+def k_array(K):
+    """3x3 camera matrix -> C double[9]."""
+    import numpy as np
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+    return (ctypes.c_double * 9)(*K.tolist())

@@ -1,0 +1,217 @@
+"""Batched entry points over the C ABI: many independent PnP problems per call.
+
+`solve_pnp_batch` is the batched counterpart of `PNP_SOLVER.solve_pnp`
+(reference: scripts/PNP_SOLVER_LIB.py:144-203).  Inputs may be NumPy arrays (host memory:
+the library stages them through device buffers) or torch tensors on a HIP device (device
+memory: zero-copy, enqueued on torch's current stream).  Either way the arithmetic runs in
+the HIP kernels of libpnp_hip.so; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+METHODS = ("qeif", "dlt")
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+def make_params(**overrides) -> _lib.QeifParams:
+    """QEIF tunables: reference defaults (PNP_SOLVER_LIB.py:2791-2794, :2836, :2845-2846,
+    :2857, :2863, :2952) with keyword overrides, e.g. make_params(max_it=5, rel_tol=0.0)."""
+    p = _lib.default_params()
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise TypeError("unknown QEIF parameter %r" % k)
+        setattr(p, k, v)
+    return p
+
+
+def _shapes(uv_shape, xyz_shape):
+    if len(uv_shape) != 3 or uv_shape[2] != 2:
+        raise ValueError("uv must have shape (B, N, 2), got %s" % (tuple(uv_shape),))
+    B, N = int(uv_shape[0]), int(uv_shape[1])
+    if tuple(xyz_shape) == (N, 3):
+        return B, N, 0, 1
+    if tuple(xyz_shape) == (B, N, 3):
+        return B, N, 3 * N, 1
+    raise ValueError("xyz must have shape (N, 3) or (B, N, 3) with B=%d, N=%d; got %s"
+                     % (B, N, tuple(xyz_shape)))
+
+
+def solve_pnp_batch(uv, xyz, K, *, method="qeif", params=None, num_it=3, want_rpy=True,
+                    patterns=None):
+    """Solve B independent PnP problems.
+
+    uv       (B, N, 2) float32 pixel coordinates
+    xyz      (N, 3) pattern shared by all problems, or (B, N, 3) one pattern per problem
+    K        (3, 3) camera matrix (float64, host)
+    method   "qeif": quaternion information filter, the reference's live solver
+             (solve_pnp_QEIF_single_pattern, :2771-3025);
+             "dlt": iterated linear DLT (solve_pnp_single_pattern, :205-430)
+    params   QEIF tunables from make_params(); None = reference defaults
+    num_it   DLT rounds (reference: 3)
+    patterns optional (P, N, 3): QEIF against P shared patterns, keeping per problem the first
+             with the smallest residual (the pattern loop of solve_pnp, :166-199); `xyz` is
+             then ignored and the result gains "pattern_id"
+
+    Returns a dict: R (B,3,3), t (B,3), t3 (B,), res_norm (B,), rpy_deg (B,3) = roll, yaw, pitch
+    in the reference's tuple order (if want_rpy), iters (B,) int32 (QEIF only).  Arrays are
+    float32 of the same kind (NumPy / torch on the same device) as `uv`.
+    """
+    if method not in METHODS:
+        raise ValueError("method must be one of %s" % (METHODS,))
+    if patterns is not None and method != "qeif":
+        raise ValueError("multiple patterns are supported by method='qeif' only")
+    lib = _lib.load()
+    Kc = _lib.k_array(K)
+    if _is_torch(uv):
+        return _solve_torch(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns)
+    return _solve_numpy(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns)
+
+
+def _solve_numpy(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns):
+    uv = np.ascontiguousarray(uv, dtype=np.float32)
+    src = patterns if patterns is not None else xyz
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    if patterns is not None:
+        if src.ndim != 3 or src.shape[1:] != (uv.shape[1], 3):
+            raise ValueError("patterns must have shape (P, N, 3)")
+        B, N, stride, n_pat = int(uv.shape[0]), int(uv.shape[1]), 0, int(src.shape[0])
+    else:
+        B, N, stride, n_pat = _shapes(uv.shape, src.shape)
+    out = dict(R=np.empty((B, 3, 3), np.float32), t=np.empty((B, 3), np.float32),
+               res_norm=np.empty(B, np.float32))
+    rpy = np.empty((B, 3), np.float32) if want_rpy else None
+    iters = np.empty(B, np.int32) if method == "qeif" else None
+    pid = np.empty(B, np.int32) if patterns is not None else None
+
+    def ptr(a):
+        return None if a is None else a.ctypes.data
+
+    _call(lib, method, ptr(uv), ptr(src), stride, n_pat, Kc, B, N, params, num_it, ptr(out["R"]),
+          ptr(out["t"]), ptr(out["res_norm"]), ptr(iters), ptr(rpy), ptr(pid), _lib.PTR_HOST, None,
+          patterns is not None)
+    out["t3"] = out["t"][:, 2].copy()
+    if rpy is not None:
+        out["rpy_deg"] = rpy
+    if iters is not None:
+        out["iters"] = iters
+    if pid is not None:
+        out["pattern_id"] = pid
+    return out
+
+
+def _solve_torch(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns):
+    import torch
+
+    if not uv.is_cuda:
+        raise ValueError("torch inputs must live on a HIP device (got %s); pass NumPy arrays for "
+                         "host memory" % uv.device)
+    src = patterns if patterns is not None else xyz
+    if not _is_torch(src):
+        src = torch.as_tensor(np.ascontiguousarray(src, dtype=np.float32), device=uv.device)
+    if uv.dtype != torch.float32 or src.dtype != torch.float32:
+        raise TypeError("uv and xyz must be float32 tensors")
+    if src.device != uv.device:
+        raise ValueError("uv and xyz must be on the same device")
+    uv = uv.contiguous()
+    src = src.contiguous()
+    if patterns is not None:
+        if src.dim() != 3 or tuple(src.shape[1:]) != (uv.shape[1], 3):
+            raise ValueError("patterns must have shape (P, N, 3)")
+        B, N, stride, n_pat = int(uv.shape[0]), int(uv.shape[1]), 0, int(src.shape[0])
+    else:
+        B, N, stride, n_pat = _shapes(tuple(uv.shape), tuple(src.shape))
+    dev = uv.device
+    with torch.cuda.device(dev):
+        out = dict(R=torch.empty((B, 3, 3), dtype=torch.float32, device=dev),
+                   t=torch.empty((B, 3), dtype=torch.float32, device=dev),
+                   res_norm=torch.empty(B, dtype=torch.float32, device=dev))
+        rpy = torch.empty((B, 3), dtype=torch.float32, device=dev) if want_rpy else None
+        iters = torch.empty(B, dtype=torch.int32, device=dev) if method == "qeif" else None
+        pid = torch.empty(B, dtype=torch.int32, device=dev) if patterns is not None else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+
+        def ptr(a):
+            return None if a is None else a.data_ptr()
+
+        _call(lib, method, ptr(uv), ptr(src), stride, n_pat, Kc, B, N, params, num_it, ptr(out["R"]),
+              ptr(out["t"]), ptr(out["res_norm"]), ptr(iters), ptr(rpy), ptr(pid), _lib.PTR_DEVICE,
+              stream, patterns is not None)
+    out["t3"] = out["t"][:, 2]
+    if rpy is not None:
+        out["rpy_deg"] = rpy
+    if iters is not None:
+        out["iters"] = iters
+    if pid is not None:
+        out["pattern_id"] = pid
+    return out
+
+
+def _call(lib, method, uv, xyz, stride, n_pat, Kc, B, N, params, num_it, R, t, res, iters, rpy, pid,
+          kind, stream, multi):
+    pref = ctypes.byref(params) if params is not None else None
+    if method == "dlt":
+        rc = lib.pnp_dlt_batch_f32(uv, xyz, stride, Kc, B, N, int(num_it), R, t, res, rpy, kind, stream)
+    elif multi:
+        rc = lib.pnp_qeif_multi_batch_f32(uv, xyz, n_pat, Kc, B, N, pref, R, t, res, iters, rpy, pid,
+                                          kind, stream)
+    else:
+        rc = lib.pnp_qeif_batch_f32(uv, xyz, stride, Kc, B, N, pref, R, t, res, iters, rpy, kind, stream)
+    _lib.check(rc)
+
+
+def euler_deg_batch(R):
+    """(B,3,3) or (B,9) float32 rotation matrices -> (B,3) roll, yaw, pitch in degrees
+    (get_Euler_from_rotation_matrix(..., is_degree=True), :4474-4517), on the device."""
+    lib = _lib.load()
+    if _is_torch(R):
+        import torch
+        if not R.is_cuda or R.dtype != torch.float32:
+            raise TypeError("R must be a float32 tensor on a HIP device")
+        R = R.contiguous()
+        B = R.numel() // 9
+        with torch.cuda.device(R.device):
+            out = torch.empty((B, 3), dtype=torch.float32, device=R.device)
+            _lib.check(lib.pnp_euler_deg_f32(R.data_ptr(), B, out.data_ptr(), _lib.PTR_DEVICE,
+                                             torch.cuda.current_stream(R.device).cuda_stream))
+        return out
+    R = np.ascontiguousarray(R, dtype=np.float32)
+    B = R.size // 9
+    out = np.empty((B, 3), np.float32)
+    _lib.check(lib.pnp_euler_deg_f32(R.ctypes.data, B, out.ctypes.data, _lib.PTR_HOST, None))
+    return out
+
+
+def shard_bounds(total: int, rank: int, world_size: int):
+    """Contiguous slice [lo, hi) of `total` problems owned by `rank`: sizes differ by at most
+    one and the slices tile [0, total) in rank order.  Problems are independent, so a
+    multi-GPU run is this slice per rank with no exchange on the data path."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank %d outside [0, %d)" % (rank, world_size))
+    base, extra = divmod(int(total), int(world_size))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_results(local: dict, group=None) -> dict:
+    """Optional collective after a sharded solve: all-gather every rank's result arrays
+    (torch tensors of equal per-rank length) in rank order.  Uses torch.distributed, i.e.
+    RCCL over xGMI for HIP tensors and gloo for CPU tensors."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    out = {}
+    for key, val in local.items():
+        val = val.contiguous()
+        buf = torch.empty((world * val.shape[0],) + tuple(val.shape[1:]), dtype=val.dtype, device=val.device)
+        dist.all_gather_into_tensor(buf, val, group=group)
+        out[key] = buf
+    return out

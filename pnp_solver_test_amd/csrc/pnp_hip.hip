@@ -1,0 +1,462 @@
+// Host side of libpnp_hip.so: argument checking, launch geometry, host-pointer staging and
+// the extern "C" entry points declared in include/pnp_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <atomic>
+#include <mutex>
+
+#include "pnp_hip.h"
+#include "pnp_kernels.hpp"
+
+namespace {
+
+using pnp::kBlock;
+
+constexpr int kMaxPoints = 512;          // LPI = 64 keeps 4 problems x 20 B x 512 points in LDS
+constexpr int kLdsBudget = 48 * 1024;    // bytes of dynamic LDS a launch may ask for
+constexpr int kMaxDevices = 64;
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(PNP_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                                \
+    } while (0)
+
+std::atomic<int> g_forced_lpi{0};
+
+// ---- per-device staging for host-pointer calls -------------------------------------------
+
+struct Staging {
+    std::mutex mu;
+    void *buf = nullptr;
+    size_t cap = 0;
+};
+Staging g_staging[kMaxDevices];
+
+// Grow-only device buffer of the current device; caller holds st.mu.
+int staging_reserve(Staging &st, size_t bytes)
+{
+    if (bytes <= st.cap) return PNP_OK;
+    if (st.buf) HIP_TRY(hipFree(st.buf));
+    st.buf = nullptr;
+    st.cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(hipMalloc(&st.buf, want));
+    st.cap = want;
+    return PNP_OK;
+}
+
+// Carves 256-byte-aligned pieces out of one buffer.
+struct Carver {
+    char *base;
+    size_t off = 0;
+    explicit Carver(void *b) : base(static_cast<char *>(b)) {}
+    template <typename T>
+    T *take(size_t count)
+    {
+        T *p = reinterpret_cast<T *>(base + off);
+        off += (count * sizeof(T) + 255) & ~static_cast<size_t>(255);
+        return p;
+    }
+};
+
+// ---- small host helpers --------------------------------------------------------------------
+
+// First two rows of K^-1 in float64 by the adjugate.
+int kinv_rows(const double K[9], pnp::KinvRows &ki)
+{
+    const double a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], i = K[8];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    if (!(det != 0.0) || !isfinite(det)) return fail(PNP_E_ARG, "camera matrix K is singular or not finite");
+    const double r = 1.0 / det;
+    ki.a00 = (e * i - f * h) * r;
+    ki.a01 = (c * h - b * i) * r;
+    ki.a02 = (b * f - c * e) * r;
+    ki.a10 = (f * g - d * i) * r;
+    ki.a11 = (a * i - c * g) * r;
+    ki.a12 = (c * d - a * f) * r;
+    return PNP_OK;
+}
+
+size_t lds_bytes(int lpi, int N, bool per_problem_xyz, int n_patterns)
+{
+    const size_t pb = kBlock / lpi;
+    const size_t uv = pb * 2 * N;
+    const size_t xyz = per_problem_xyz ? pb * 3 * N : static_cast<size_t>(n_patterns) * 3 * N;
+    return (uv + xyz) * sizeof(float);
+}
+
+// Lanes per problem.  The floor is set by LDS: a workgroup's correspondences must fit the
+// budget.  Above the floor, more lanes per problem only pay when the batch is too small to
+// give every lane of the chip its own problem.
+int choose_lpi(int64_t B, int N, bool per_problem_xyz, int n_patterns)
+{
+    int forced = g_forced_lpi.load();
+    int lpi = 1;
+    while (lpi < 64 && lds_bytes(lpi, N, per_problem_xyz, n_patterns) > kLdsBudget) lpi *= 2;
+    if (forced > 0) return forced > lpi ? forced : lpi;
+    const int64_t chip_lanes = 256LL * 64 * 8;  // CUs x wave width x resident waves aimed for
+    while (lpi < 64 && 2 * lpi <= N && B * lpi * 2 <= chip_lanes) lpi *= 2;
+    return lpi;
+}
+
+int check_common(const float *uv, const float *xyz, int64_t xyz_stride, const double *K, int64_t B,
+                 int32_t N, const float *R_out, const float *t_out, int32_t ptr_kind)
+{
+    if (B < 0) return fail(PNP_E_ARG, "B = %lld is negative", static_cast<long long>(B));
+    if (N < 1 || N > kMaxPoints) return fail(PNP_E_ARG, "N = %d outside [1, %d]", N, kMaxPoints);
+    if (!K) return fail(PNP_E_ARG, "K is NULL");
+    if (ptr_kind != PNP_PTR_HOST && ptr_kind != PNP_PTR_DEVICE)
+        return fail(PNP_E_ARG, "ptr_kind = %d is neither PNP_PTR_HOST nor PNP_PTR_DEVICE", ptr_kind);
+    if (B > 0 && (!uv || !xyz || !R_out || !t_out))
+        return fail(PNP_E_ARG, "uv, xyz, R_out and t_out must not be NULL");
+    if (xyz_stride != 0 && xyz_stride < 3 * static_cast<int64_t>(N))
+        return fail(PNP_E_ARG, "xyz_problem_stride = %lld is neither 0 nor >= 3*N",
+                    static_cast<long long>(xyz_stride));
+    return PNP_OK;
+}
+
+pnp::QeifParams to_device_params(const pnp_qeif_params *p)
+{
+    pnp_qeif_params d;
+    pnp_qeif_default_params(&d);
+    if (p) d = *p;
+    pnp::QeifParams q;
+    q.q_inv = d.q_inv;
+    q.r_quat = d.r_quat;
+    q.r_delta = d.r_delta;
+    q.omega0 = d.omega0;
+    q.rel_tol = d.rel_tol;
+    q.res_old0 = d.res_old0;
+    q.max_it = d.max_it;
+    return q;
+}
+
+// ---- launchers (device pointers only) ---------------------------------------------------------
+
+template <int LPI, int NCT>
+void launch_qeif_t(dim3 grid, size_t lds, hipStream_t s, const float *uv, const float *xyz,
+                   int64_t xyz_stride, int n_patterns, const pnp::KinvRows &ki, int64_t B, int N,
+                   const pnp::QeifParams &p, float *R, float *t, float *res, int32_t *iters,
+                   float *rpy, int32_t *pid)
+{
+    hipLaunchKernelGGL((pnp::qeif_kernel<LPI, NCT>), grid, dim3(kBlock), lds, s, uv, xyz, xyz_stride,
+                       n_patterns, ki, B, N, p, R, t, res, iters, rpy, pid);
+}
+
+int launch_qeif(hipStream_t s, const float *uv, const float *xyz, int64_t xyz_stride, int n_patterns,
+                const pnp::KinvRows &ki, int64_t B, int N, const pnp::QeifParams &p, float *R,
+                float *t, float *res, int32_t *iters, float *rpy, int32_t *pid)
+{
+    if (B == 0) return PNP_OK;
+    const int lpi = choose_lpi(B, N, xyz_stride != 0, n_patterns);
+    const size_t lds = lds_bytes(lpi, N, xyz_stride != 0, n_patterns);
+    if (lds > 64 * 1024)
+        return fail(PNP_E_ARG, "N = %d with %d pattern(s) needs %zu bytes of LDS per workgroup (max 65536)",
+                    N, n_patterns, lds);
+    const int64_t pb = kBlock / lpi;
+    const int64_t nblk = (B + pb - 1) / pb;
+    if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
+    const dim3 grid(static_cast<unsigned>(nblk));
+#define PNP_Q(LPI_, NCT_)                                                                             \
+    launch_qeif_t<LPI_, NCT_>(grid, lds, s, uv, xyz, xyz_stride, n_patterns, ki, B, N, p, R, t, res, \
+                              iters, rpy, pid)
+    switch (lpi) {
+    case 1:
+        if (N == 6) PNP_Q(1, 6); else PNP_Q(1, 0);
+        break;
+    case 2: PNP_Q(2, 0); break;
+    case 4: PNP_Q(4, 0); break;
+    case 8: PNP_Q(8, 0); break;
+    case 16: PNP_Q(16, 0); break;
+    case 32: PNP_Q(32, 0); break;
+    default: PNP_Q(64, 0); break;
+    }
+#undef PNP_Q
+    HIP_TRY(hipGetLastError());
+    return PNP_OK;
+}
+
+template <int LPI, int NCT>
+void launch_dlt_t(dim3 grid, size_t lds, hipStream_t s, const float *uv, const float *xyz,
+                  int64_t xyz_stride, const pnp::KinvRows &ki, int64_t B, int N, int num_it, float *R,
+                  float *t, float *res, float *rpy)
+{
+    hipLaunchKernelGGL((pnp::dlt_kernel<LPI, NCT>), grid, dim3(kBlock), lds, s, uv, xyz, xyz_stride, ki,
+                       B, N, num_it, R, t, res, rpy);
+}
+
+int launch_dlt(hipStream_t s, const float *uv, const float *xyz, int64_t xyz_stride,
+               const pnp::KinvRows &ki, int64_t B, int N, int num_it, float *R, float *t, float *res,
+               float *rpy)
+{
+    if (B == 0) return PNP_OK;
+    const int lpi = choose_lpi(B, N, xyz_stride != 0, 1);
+    const size_t lds = lds_bytes(lpi, N, xyz_stride != 0, 1);
+    if (lds > 64 * 1024) return fail(PNP_E_ARG, "N = %d needs %zu bytes of LDS per workgroup (max 65536)", N, lds);
+    const int64_t pb = kBlock / lpi;
+    const int64_t nblk = (B + pb - 1) / pb;
+    if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
+    const dim3 grid(static_cast<unsigned>(nblk));
+#define PNP_D(LPI_, NCT_) \
+    launch_dlt_t<LPI_, NCT_>(grid, lds, s, uv, xyz, xyz_stride, ki, B, N, num_it, R, t, res, rpy)
+    switch (lpi) {
+    case 1:
+        if (N == 6) PNP_D(1, 6); else PNP_D(1, 0);
+        break;
+    case 2: PNP_D(2, 0); break;
+    case 4: PNP_D(4, 0); break;
+    case 8: PNP_D(8, 0); break;
+    case 16: PNP_D(16, 0); break;
+    case 32: PNP_D(32, 0); break;
+    default: PNP_D(64, 0); break;
+    }
+#undef PNP_D
+    HIP_TRY(hipGetLastError());
+    return PNP_OK;
+}
+
+// ---- host-pointer wrapper ----------------------------------------------------------------------
+
+struct SolveIO {
+    const float *uv;
+    const float *xyz;
+    float *R, *t, *res, *rpy;
+    int32_t *iters, *pid;
+};
+
+// Copies the inputs of a host-pointer call to the device, runs `run` on device pointers and
+// copies the requested outputs back.  Synchronises the stream before returning.
+template <typename Run>
+int with_host_staging(hipStream_t s, int64_t B, int32_t N, size_t xyz_floats, const SolveIO &h,
+                      Run run)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(PNP_E_HIP, "device index %d out of range", dev);
+    Staging &st = g_staging[dev];
+    std::lock_guard<std::mutex> lock(st.mu);
+    const size_t nB = static_cast<size_t>(B);
+    const size_t total = 256 * 10 + (nB * 2 * N + xyz_floats + nB * (9 + 3 + 1 + 3)) * sizeof(float) +
+                         2 * nB * sizeof(int32_t);
+    int rc = staging_reserve(st, total);
+    if (rc) return rc;
+    Carver c(st.buf);
+    SolveIO d;
+    float *d_uv = c.take<float>(nB * 2 * N);
+    float *d_xyz = c.take<float>(xyz_floats);
+    d.uv = d_uv;
+    d.xyz = d_xyz;
+    d.R = c.take<float>(nB * 9);
+    d.t = c.take<float>(nB * 3);
+    d.res = c.take<float>(nB);
+    d.rpy = h.rpy ? c.take<float>(nB * 3) : nullptr;
+    d.iters = h.iters ? c.take<int32_t>(nB) : nullptr;
+    d.pid = h.pid ? c.take<int32_t>(nB) : nullptr;
+    HIP_TRY(hipMemcpyAsync(d_uv, h.uv, nB * 2 * N * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_xyz, h.xyz, xyz_floats * sizeof(float), hipMemcpyHostToDevice, s));
+    rc = run(d);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h.R, d.R, nB * 9 * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h.t, d.t, nB * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (h.res) HIP_TRY(hipMemcpyAsync(h.res, d.res, nB * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (h.rpy) HIP_TRY(hipMemcpyAsync(h.rpy, d.rpy, nB * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (h.iters) HIP_TRY(hipMemcpyAsync(h.iters, d.iters, nB * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (h.pid) HIP_TRY(hipMemcpyAsync(h.pid, d.pid, nB * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return PNP_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+
+extern "C" {
+
+void pnp_qeif_default_params(pnp_qeif_params *p)
+{
+    if (!p) return;
+    p->q_inv = (225.68 * 225.68) / 9.0;
+    p->r_quat = 0.1;
+    p->r_delta = 0.01;
+    p->omega0 = 1e-5;
+    p->max_it = 14;
+    p->rel_tol = 1e-2;
+    p->res_old0 = 1e-7;
+}
+
+int pnp_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e == hipErrorNoDevice) return 0;
+    if (e != hipSuccess) return fail(PNP_E_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    return n;
+}
+
+int pnp_init(int device)
+{
+    const int n = pnp_device_count();
+    if (n < 0) return n;
+    if (n == 0) return fail(PNP_E_NODEVICE, "no HIP device is visible");
+    if (device < 0 || device >= n) return fail(PNP_E_ARG, "device %d outside [0, %d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(nullptr));  // forces context creation
+    return PNP_OK;
+}
+
+int pnp_qeif_multi_batch_f32(const float *uv, const float *xyz, int32_t n_patterns, const double K[9],
+                             int64_t B, int32_t N, const pnp_qeif_params *p, float *R_out,
+                             float *t_out, float *res_out, int32_t *iters_out, float *rpy_out,
+                             int32_t *pattern_id_out, int32_t ptr_kind, void *hip_stream)
+{
+    g_err[0] = 0;
+    int rc = check_common(uv, xyz, 0, K, B, N, R_out, t_out, ptr_kind);
+    if (rc) return rc;
+    if (n_patterns < 1) return fail(PNP_E_ARG, "n_patterns = %d must be >= 1", n_patterns);
+    if (p && (p->max_it < 1)) return fail(PNP_E_ARG, "max_it = %d must be >= 1", p->max_it);
+    pnp::KinvRows ki;
+    rc = kinv_rows(K, ki);
+    if (rc) return rc;
+    const pnp::QeifParams q = to_device_params(p);
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (B == 0) return PNP_OK;
+    if (ptr_kind == PNP_PTR_DEVICE)
+        return launch_qeif(s, uv, xyz, 0, n_patterns, ki, B, N, q, R_out, t_out, res_out, iters_out,
+                           rpy_out, pattern_id_out);
+    SolveIO h{uv, xyz, R_out, t_out, res_out, rpy_out, iters_out, pattern_id_out};
+    return with_host_staging(s, B, N, static_cast<size_t>(n_patterns) * 3 * N, h, [&](const SolveIO &d) {
+        return launch_qeif(s, d.uv, d.xyz, 0, n_patterns, ki, B, N, q, d.R, d.t, d.res, d.iters, d.rpy, d.pid);
+    });
+}
+
+int pnp_qeif_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_stride, const double K[9],
+                       int64_t B, int32_t N, const pnp_qeif_params *p, float *R_out, float *t_out,
+                       float *res_out, int32_t *iters_out, float *rpy_out, int32_t ptr_kind,
+                       void *hip_stream)
+{
+    g_err[0] = 0;
+    int rc = check_common(uv, xyz, xyz_problem_stride, K, B, N, R_out, t_out, ptr_kind);
+    if (rc) return rc;
+    if (p && (p->max_it < 1)) return fail(PNP_E_ARG, "max_it = %d must be >= 1", p->max_it);
+    pnp::KinvRows ki;
+    rc = kinv_rows(K, ki);
+    if (rc) return rc;
+    const pnp::QeifParams q = to_device_params(p);
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (B == 0) return PNP_OK;
+    if (ptr_kind == PNP_PTR_DEVICE)
+        return launch_qeif(s, uv, xyz, xyz_problem_stride, 1, ki, B, N, q, R_out, t_out, res_out,
+                           iters_out, rpy_out, nullptr);
+    if (xyz_problem_stride != 0 && xyz_problem_stride != 3 * static_cast<int64_t>(N))
+        return fail(PNP_E_ARG, "host-pointer calls take xyz_problem_stride 0 or 3*N only");
+    const size_t xyz_floats = xyz_problem_stride ? static_cast<size_t>(B) * 3 * N : static_cast<size_t>(3) * N;
+    SolveIO h{uv, xyz, R_out, t_out, res_out, rpy_out, iters_out, nullptr};
+    return with_host_staging(s, B, N, xyz_floats, h, [&](const SolveIO &d) {
+        return launch_qeif(s, d.uv, d.xyz, xyz_problem_stride, 1, ki, B, N, q, d.R, d.t, d.res, d.iters,
+                           d.rpy, nullptr);
+    });
+}
+
+int pnp_dlt_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_stride, const double K[9],
+                      int64_t B, int32_t N, int32_t num_it, float *R_out, float *t_out, float *res_out,
+                      float *rpy_out, int32_t ptr_kind, void *hip_stream)
+{
+    g_err[0] = 0;
+    int rc = check_common(uv, xyz, xyz_problem_stride, K, B, N, R_out, t_out, ptr_kind);
+    if (rc) return rc;
+    if (num_it < 1) return fail(PNP_E_ARG, "num_it = %d must be >= 1", num_it);
+    pnp::KinvRows ki;
+    rc = kinv_rows(K, ki);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (B == 0) return PNP_OK;
+    if (ptr_kind == PNP_PTR_DEVICE)
+        return launch_dlt(s, uv, xyz, xyz_problem_stride, ki, B, N, num_it, R_out, t_out, res_out, rpy_out);
+    if (xyz_problem_stride != 0 && xyz_problem_stride != 3 * static_cast<int64_t>(N))
+        return fail(PNP_E_ARG, "host-pointer calls take xyz_problem_stride 0 or 3*N only");
+    const size_t xyz_floats = xyz_problem_stride ? static_cast<size_t>(B) * 3 * N : static_cast<size_t>(3) * N;
+    SolveIO h{uv, xyz, R_out, t_out, res_out, rpy_out, nullptr, nullptr};
+    return with_host_staging(s, B, N, xyz_floats, h, [&](const SolveIO &d) {
+        return launch_dlt(s, d.uv, d.xyz, xyz_problem_stride, ki, B, N, num_it, d.R, d.t, d.res, d.rpy);
+    });
+}
+
+int pnp_euler_deg_f32(const float *R, int64_t B, float *rpy, int32_t ptr_kind, void *hip_stream)
+{
+    g_err[0] = 0;
+    if (B < 0) return fail(PNP_E_ARG, "B = %lld is negative", static_cast<long long>(B));
+    if (ptr_kind != PNP_PTR_HOST && ptr_kind != PNP_PTR_DEVICE)
+        return fail(PNP_E_ARG, "ptr_kind = %d is neither PNP_PTR_HOST nor PNP_PTR_DEVICE", ptr_kind);
+    if (B == 0) return PNP_OK;
+    if (!R || !rpy) return fail(PNP_E_ARG, "R and rpy must not be NULL");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const int64_t nblk = (B + kBlock - 1) / kBlock;
+    if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
+    if (ptr_kind == PNP_PTR_DEVICE) {
+        hipLaunchKernelGGL(pnp::euler_kernel, dim3(static_cast<unsigned>(nblk)), dim3(kBlock), 0, s, R, B, rpy);
+        HIP_TRY(hipGetLastError());
+        return PNP_OK;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(PNP_E_HIP, "device index %d out of range", dev);
+    Staging &st = g_staging[dev];
+    std::lock_guard<std::mutex> lock(st.mu);
+    const size_t nB = static_cast<size_t>(B);
+    int rc = staging_reserve(st, 1024 + nB * 12 * sizeof(float));
+    if (rc) return rc;
+    Carver c(st.buf);
+    float *d_R = c.take<float>(nB * 9);
+    float *d_rpy = c.take<float>(nB * 3);
+    HIP_TRY(hipMemcpyAsync(d_R, R, nB * 9 * sizeof(float), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(pnp::euler_kernel, dim3(static_cast<unsigned>(nblk)), dim3(kBlock), 0, s, d_R, B, d_rpy);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rpy, d_rpy, nB * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return PNP_OK;
+}
+
+int pnp_set_lanes_per_problem(int32_t lanes)
+{
+    g_err[0] = 0;
+    if (lanes != 0 && (lanes < 1 || lanes > 64 || (lanes & (lanes - 1)) != 0))
+        return fail(PNP_E_ARG, "lanes = %d is not 0 or a power of two in [1, 64]", lanes);
+    g_forced_lpi.store(lanes);
+    return PNP_OK;
+}
+
+int pnp_get_lanes_per_problem(int64_t B, int32_t N, int64_t xyz_problem_stride)
+{
+    if (N < 1 || N > kMaxPoints) return fail(PNP_E_ARG, "N = %d outside [1, %d]", N, kMaxPoints);
+    return choose_lpi(B, N, xyz_problem_stride != 0, 1);
+}
+
+int pnp_max_points(void) { return kMaxPoints; }
+
+const char *pnp_last_error(void) { return g_err; }
+
+const char *pnp_version(void) { return "pnp_hip 0.1 (gfx950)"; }
+
+}  // extern "C"

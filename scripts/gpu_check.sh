@@ -1,0 +1,23 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): smoke, GPU parity tests, bench, kernel-trace profile.
+# Every GPU step has its own time limit; a fault, abort or time-out ends the script.
+set -u
+cd "${GRAFT_REPO_ROOT:-.}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+step() {   # step <seconds> <log> <cmd...>
+    local secs=$1 log=$2; shift 2
+    echo "== $* (limit ${secs}s)" | tee -a gpurun_out/steps.log
+    timeout -k 10 "$secs" "$@" > "gpurun_out/$log" 2>&1
+    local rc=$?
+    echo "   exit $rc" | tee -a gpurun_out/steps.log
+    case $rc in 124|137|134|139) echo "stopping: step ended abnormally" | tee -a gpurun_out/steps.log; tail -20 "gpurun_out/$log"; exit $rc;; esac
+    return $rc
+}
+: > gpurun_out/steps.log
+step 240 smoke.log python -u -c "import __graft_entry__ as g; g.smoke()" || { tail -30 gpurun_out/smoke.log; exit 1; }
+tail -2 gpurun_out/smoke.log
+step 600 pytest_gpu.log python -u -m pytest tests -m gpu -q --timeout 180 --timeout-method thread -p no:cacheprovider
+tail -25 gpurun_out/pytest_gpu.log
+step 300 bench.log python -u bench.py --steps 20 --warmup 3 || { tail -30 gpurun_out/bench.log; exit 1; }
+tail -3 gpurun_out/bench.log

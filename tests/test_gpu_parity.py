@@ -1,0 +1,552 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the reference-generated
+golden vectors.  Needs an MI355X: run with `-m gpu`.
+
+Stated tolerances (float32 I/O, float64 arithmetic):
+  rotation geodesic angle <= 1e-5 rad, |dt|/|t| <= 1e-4 against the REFERENCE (golden files;
+  includes the float32 rounding of the pattern coordinates the device path applies);
+  on bit-identical float32 inputs against the oracle the asserted bounds are far tighter:
+  |dR| <= 5e-7 per entry (one float32 rounding of the output), |dt|/|t| <= 1e-6, iteration
+  counts equal.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import pnp_solver_test_amd as pnp
+from conftest import lm6_indices, rel_t, rot_angle
+from oracle import c_oracle, pnp_oracle as po
+from pnp_solver_test_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+K = po.K_DEFAULT
+P6 = po.pattern_array(po.PATTERN_ALEXANDER, po.LM6_KEYS)
+P6f = P6.astype(np.float32)
+P15 = po.pattern_array(po.PATTERN_ALEXANDER)
+
+ANG_TOL = 1e-5       # rad, vs reference
+RELT_TOL = 1e-4      # vs reference
+DR_TIGHT = 5e-7      # vs oracle on identical inputs
+RELT_TIGHT = 1e-6
+
+
+@pytest.fixture(scope="module")
+def torch_dev():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    assert pnp.device_count() >= 1
+    _lib.load().pnp_set_lanes_per_problem(0)
+    return torch.device("cuda:0")
+
+
+def to_dev(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+
+def to_np(out):
+    return {k: v.detach().cpu().numpy() for k, v in out.items()}
+
+
+def solve_dev(uv, xyz, dev, **kw):
+    """Device-pointer path: torch tensors in HBM, results copied back for checking."""
+    import torch
+    pats = kw.pop("patterns", None)
+    out = pnp.solve_pnp_batch(to_dev(uv, dev), None if xyz is None else to_dev(xyz, dev), K,
+                              patterns=None if pats is None else to_dev(pats, dev), **kw)
+    torch.cuda.synchronize()
+    return to_np(out)
+
+
+def assert_tight(out, ref, mask=None):
+    m = slice(None) if mask is None else mask
+    assert np.abs(out["R"].astype(np.float64) - ref["R"])[m].max() <= DR_TIGHT
+    assert rel_t(out["t"][m], ref["t"][m]).max() <= RELT_TIGHT
+    assert np.abs(out["res_norm"].astype(np.float64) - ref["res_norm"])[m].max() <= 1e-6 * max(1.0, np.abs(ref["res_norm"][m]).max())
+
+
+def stress_uv6(golden):
+    g = golden("stress_qeif_n6")
+    return g, np.ascontiguousarray(g["uv15"][:, lm6_indices(g), :])
+
+
+# ---------------------------------------------------------------------------------------------
+# QEIF
+# ---------------------------------------------------------------------------------------------
+
+def test_qeif_n6_against_reference_and_oracle(golden, torch_dev):
+    g, uv = stress_uv6(golden)
+    out = solve_dev(uv, P6f, torch_dev)
+    # reference (pattern in exact float64 there, float32 here)
+    assert rot_angle(out["R"], g["R"]).max() <= ANG_TOL
+    assert rel_t(out["t"], g["t"]).max() <= RELT_TOL
+    assert (out["iters"] == g["iters"]).mean() >= 0.9995
+    same = out["iters"] == g["iters"]
+    rpy_ref = np.stack([g["roll"], g["yaw"], g["pitch"]], axis=1)
+    assert np.abs(out["rpy_deg"] - rpy_ref)[same].max() <= 1e-3          # degrees
+    assert np.abs(out["res_norm"] - g["res_norm"])[same].max() <= 1e-6
+    assert np.array_equal(out["t3"], out["t"][:, 2])
+    # oracle on the identical float32 inputs
+    ref = c_oracle.qeif_batch(uv.astype(np.float64), P6f.astype(np.float64), K)
+    assert np.array_equal(out["iters"], ref["iters"])
+    assert_tight(out, ref)
+    assert np.abs(out["rpy_deg"] - ref["rpy"]).max() <= 2e-4
+    # the pass criteria of the stress driver come out the same as in the reference run
+    est = np.stack([out["t3"] * 100.0, out["rpy_deg"][:, 0], out["rpy_deg"][:, 2], out["rpy_deg"][:, 1]], 1)
+    gt = np.stack([g["t_gt"][:, 2] * 100.0, g["roll_gt"], g["pitch_gt"], g["yaw_gt"]], 1)
+    assert (np.abs(est - gt) < 10.0).tolist() == g["passed"].tolist()
+
+
+def test_qeif_n6_exact_inputs(golden, torch_dev):
+    g = golden("qeif_n6_exact")
+    out = solve_dev(g["uv"], P6f, torch_dev)
+    ref = c_oracle.qeif_batch(g["uv"].astype(np.float64), P6f.astype(np.float64), K)
+    assert np.array_equal(out["iters"], ref["iters"])
+    assert_tight(out, ref)
+    same = out["iters"] == g["iters"]
+    assert same.mean() >= 0.99
+    assert rot_angle(out["R"], g["R"])[same].max() <= ANG_TOL
+    assert rel_t(out["t"], g["t"])[same].max() <= RELT_TOL
+
+
+@pytest.mark.parametrize("lanes", [0, 4, 8, 16, 32, 64])
+def test_qeif_n68(golden, torch_dev, lanes):
+    g = golden("qeif_n68")
+    lib = _lib.load()
+    lib.pnp_set_lanes_per_problem(lanes)
+    try:
+        xyz = g["xyz"].astype(np.float32)
+        out = solve_dev(g["uv"], xyz, torch_dev)
+    finally:
+        lib.pnp_set_lanes_per_problem(0)
+    assert rot_angle(out["R"], g["R"]).max() <= ANG_TOL
+    assert rel_t(out["t"], g["t"]).max() <= RELT_TOL
+    ref = c_oracle.qeif_batch(g["uv"].astype(np.float64), xyz.astype(np.float64), K)
+    assert np.array_equal(out["iters"], ref["iters"])
+    assert_tight(out, ref)
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 32, 64])
+def test_qeif_every_lane_mapping_agrees(golden, torch_dev, lanes):
+    """LPI = 64 is one wavefront per problem, LPI = 1 one lane per problem: same answers."""
+    g, uv = stress_uv6(golden)
+    uv = uv[:1500]
+    lib = _lib.load()
+    ref = c_oracle.qeif_batch(uv.astype(np.float64), P6f.astype(np.float64), K)
+    lib.pnp_set_lanes_per_problem(lanes)
+    try:
+        shared = solve_dev(uv, P6f, torch_dev)
+        own = solve_dev(uv, np.broadcast_to(P6f, (len(uv), 6, 3)), torch_dev)
+    finally:
+        lib.pnp_set_lanes_per_problem(0)
+    for out in (shared, own):
+        assert np.array_equal(out["iters"], ref["iters"])
+        assert_tight(out, ref)
+    assert np.array_equal(shared["R"], own["R"]) and np.array_equal(shared["t"], own["t"])
+
+
+def test_qeif_per_problem_patterns(torch_dev):
+    """Every problem has its own (perturbed) pattern, as the north-star data layout has it."""
+    rng = np.random.default_rng(5)
+    B = 3000
+    xyz = (P6[None] + rng.normal(0.0, 0.003, (B, 6, 3))).astype(np.float32)
+    roll, pitch, yaw, t = po.sample_random_stress_poses(rng, B)
+    uv = np.stack([po.project(xyz[i].astype(np.float64), K, po.euler_to_R(roll[i], yaw[i], pitch[i], True),
+                              t[i], True) for i in range(B)]).astype(np.float32)
+    out = solve_dev(uv, xyz, torch_dev)
+    ref = c_oracle.qeif_batch(uv.astype(np.float64), xyz.astype(np.float64), K)
+    assert np.array_equal(out["iters"], ref["iters"])
+    assert_tight(out, ref)
+
+
+def test_qeif_custom_params_fixed_five_iterations(golden, torch_dev):
+    g, uv = stress_uv6(golden)
+    uv = uv[:2000]
+    out = solve_dev(uv, P6f, torch_dev, params=pnp.make_params(max_it=5, rel_tol=0.0))
+    ref = c_oracle.qeif_batch(uv.astype(np.float64), P6f.astype(np.float64), K, max_it=5, rel_tol=0.0)
+    assert (out["iters"] == 5).all() and (ref["iters"] == 5).all()
+    assert_tight(out, ref)
+    out2 = solve_dev(uv, P6f, torch_dev, params=pnp.make_params(q_inv=1000.0, r_quat=0.05, omega0=1e-3))
+    ref2 = c_oracle.qeif_batch(uv.astype(np.float64), P6f.astype(np.float64), K, q_inv=1000.0, r_quat=0.05,
+                               omega0=1e-3)
+    assert np.array_equal(out2["iters"], ref2["iters"])
+    assert_tight(out2, ref2)
+
+
+def test_multi_pattern_selection(golden, torch_dev):
+    g = golden("multi_pattern")
+    pats = g["xyz"].astype(np.float32)
+    out = solve_dev(g["uv"], None, torch_dev, patterns=pats)
+    assert np.array_equal(out["pattern_id"], g["pattern_id"])
+    assert rot_angle(out["R"], g["R"]).max() <= ANG_TOL
+    assert rel_t(out["t"], g["t"]).max() <= RELT_TOL
+    host = pnp.solve_pnp_batch(g["uv"], None, K, patterns=pats)          # host-pointer path
+    assert np.array_equal(host["pattern_id"], out["pattern_id"]) and np.array_equal(host["R"], out["R"])
+
+
+# ---------------------------------------------------------------------------------------------
+# DLT
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("tag,P", [("dlt_n6", P6), ("dlt_n15", P15)])
+def test_dlt_against_reference_and_oracle(golden, torch_dev, tag, P):
+    g = golden(tag)
+    Pf = P.astype(np.float32)
+    out = solve_dev(g["uv"], Pf, torch_dev, method="dlt")
+    ref = c_oracle.dlt_batch(g["uv"].astype(np.float64), Pf.astype(np.float64), K)
+    ok = ~g["raised"] & np.isfinite(g["R"]).all(axis=(1, 2)) & np.isfinite(ref["R"]).all(axis=(1, 2))
+    # away from the sign/clamp branches, which flip on rounding-level changes
+    clear = ok & (ref["margins"][:, 0] > 1e-7) & (ref["margins"][:, 1] > 1e-7) & (ref["margins"][:, 2] > 1e-6)
+    assert clear.sum() >= 0.98 * len(clear)
+    assert_tight(out, ref, clear)
+    assert np.abs(out["rpy_deg"] - ref["rpy"])[clear].max() <= 2e-3
+    assert rot_angle(out["R"], g["R"])[clear].max() <= ANG_TOL
+    assert rel_t(out["t"], g["t"])[clear].max() <= RELT_TOL
+    assert "iters" not in out
+
+
+@pytest.mark.parametrize("lanes", [1, 4, 64])
+def test_dlt_lane_mappings(golden, torch_dev, lanes):
+    g = golden("dlt_n15")
+    Pf = P15.astype(np.float32)
+    lib = _lib.load()
+    lib.pnp_set_lanes_per_problem(lanes)
+    try:
+        out = solve_dev(g["uv"][:600], Pf, torch_dev, method="dlt", num_it=3)
+        out5 = solve_dev(g["uv"][:600], Pf, torch_dev, method="dlt", num_it=5)
+    finally:
+        lib.pnp_set_lanes_per_problem(0)
+    for o, n in ((out, 3), (out5, 5)):
+        ref = c_oracle.dlt_batch(g["uv"][:600].astype(np.float64), Pf.astype(np.float64), K, num_it=n)
+        clear = np.isfinite(ref["R"]).all(axis=(1, 2)) & (ref["margins"][:, 0] > 1e-7) & (ref["margins"][:, 1] > 1e-7)
+        assert_tight(o, ref, clear)
+
+
+# ---------------------------------------------------------------------------------------------
+# Euler epilogue
+# ---------------------------------------------------------------------------------------------
+
+def test_euler_kernel(golden, torch_dev):
+    g = golden("known_cases")
+    R = g["euler_R"].astype(np.float32)
+    host = pnp.euler_deg_batch(R)
+    dev = pnp.euler_deg_batch(to_dev(R, torch_dev)).cpu().numpy()
+    assert np.array_equal(host, dev)
+    ref = c_oracle.euler_deg(R.astype(np.float64))
+    # away from gimbal lock float32 matrix entries move the angles by ~1e-5 deg at most
+    away = np.abs(R[:, 2, 1]) < 0.999
+    assert np.abs(host - ref)[away].max() <= 1e-4
+    assert np.abs(host - g["euler_out"])[away].max() <= 1e-3
+    locked = np.array([po.euler_to_R(20.0, 0.0, 90.0, True), po.euler_to_R(-35.0, 0.0, -90.0, True)], np.float32)
+    got = pnp.euler_deg_batch(locked)
+    assert np.allclose(got, c_oracle.euler_deg(locked.astype(np.float64)), atol=1e-4)
+    assert np.allclose(got[:, 2], [90.0, -90.0]) and np.all(got[:, 1] == 0.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# boundary behaviour and edge cases
+# ---------------------------------------------------------------------------------------------
+
+def test_host_and_device_pointer_paths_agree(golden, torch_dev):
+    g, uv = stress_uv6(golden)
+    for method in ("qeif", "dlt"):
+        dev = solve_dev(uv[:777], P6f, torch_dev, method=method)
+        host = pnp.solve_pnp_batch(uv[:777], P6f, K, method=method)
+        for k in dev:
+            assert np.array_equal(dev[k], host[k], equal_nan=True), (method, k)
+        assert host["R"].dtype == np.float32 and host["R"].shape == (777, 3, 3)
+
+
+@pytest.mark.parametrize("B", [1, 2, 63, 64, 255, 256, 257, 1000])
+def test_ragged_batches(golden, torch_dev, B):
+    g, uv = stress_uv6(golden)
+    full = solve_dev(uv[:1000], P6f, torch_dev)
+    lib = _lib.load()
+    lib.pnp_set_lanes_per_problem(1)
+    try:
+        part = solve_dev(uv[:B], P6f, torch_dev)
+    finally:
+        lib.pnp_set_lanes_per_problem(0)
+    ref = c_oracle.qeif_batch(uv[:B].astype(np.float64), P6f.astype(np.float64), K)
+    assert np.array_equal(part["iters"], ref["iters"])
+    assert_tight(part, ref)
+    assert np.array_equal(part["R"], full["R"][:B])
+    auto = solve_dev(uv[:B], P6f, torch_dev)            # small batches pick more lanes per problem
+    assert np.array_equal(auto["iters"], ref["iters"])
+    assert_tight(auto, ref)
+
+
+def test_empty_batch(torch_dev):
+    out = pnp.solve_pnp_batch(np.zeros((0, 6, 2), np.float32), P6f, K)
+    assert out["R"].shape == (0, 3, 3) and out["iters"].shape == (0,)
+    out = solve_dev(np.zeros((0, 6, 2), np.float32), P6f, torch_dev, method="dlt")
+    assert out["t"].shape == (0, 3)
+
+
+def test_outputs_do_not_run_past_the_batch(golden, torch_dev):
+    """Idle lanes of the last workgroup must not write: guard words after each output stay put."""
+    import torch
+    g, uv = stress_uv6(golden)
+    B = 300
+    lib = _lib.load()
+    uv_d, P_d = to_dev(uv[:B], torch_dev), to_dev(P6f, torch_dev)
+    R = torch.full((B * 9 + 64,), -7.0, device=torch_dev)
+    t = torch.full((B * 3 + 64,), -7.0, device=torch_dev)
+    res = torch.full((B + 64,), -7.0, device=torch_dev)
+    it = torch.full((B + 64,), -7, dtype=torch.int32, device=torch_dev)
+    rpy = torch.full((B * 3 + 64,), -7.0, device=torch_dev)
+    for lanes in (1, 8, 64):
+        lib.pnp_set_lanes_per_problem(lanes)
+        rc = lib.pnp_qeif_batch_f32(uv_d.data_ptr(), P_d.data_ptr(), 0, _lib.k_array(K), B, 6, None, R.data_ptr(),
+                                    t.data_ptr(), res.data_ptr(), it.data_ptr(), rpy.data_ptr(), _lib.PTR_DEVICE,
+                                    torch.cuda.current_stream().cuda_stream)
+        lib.pnp_set_lanes_per_problem(0)
+        _lib.check(rc)
+        torch.cuda.synchronize()
+        assert (R[B * 9:] == -7).all() and (t[B * 3:] == -7).all() and (res[B:] == -7).all()
+        assert (it[B:] == -7).all() and (rpy[B * 3:] == -7).all()
+        assert (it[:B] > 0).all()
+
+
+def test_nan_inputs_stay_in_their_own_problem(golden, torch_dev):
+    g, uv = stress_uv6(golden)
+    uv = uv[:512].copy()
+    clean = solve_dev(uv, P6f, torch_dev)
+    uv[100, 2, 0] = np.nan
+    uv[300] = 0.0                       # all six points on one pixel: degenerate, not an error
+    out = solve_dev(uv, P6f, torch_dev)
+    assert np.isnan(out["R"][100]).all() and 1 <= out["iters"][100] <= 14
+    keep = np.ones(512, bool)
+    keep[[100, 300]] = False
+    assert np.array_equal(out["R"][keep], clean["R"][keep]) and np.array_equal(out["t"][keep], clean["t"][keep])
+    d = solve_dev(uv, P6f, torch_dev, method="dlt")
+    dc = solve_dev(g["uv15"][:512, lm6_indices(g), :], P6f, torch_dev, method="dlt")
+    assert np.isnan(d["R"][100]).any()
+    assert np.array_equal(d["R"][keep], dc["R"][keep], equal_nan=True)
+
+
+@pytest.mark.parametrize("N", [4, 5, 7, 15, 33, 100, 512])
+def test_other_point_counts(torch_dev, N):
+    rng = np.random.default_rng(N)
+    B = 257
+    P = rng.uniform([-0.07, -0.05, -0.04], [0.07, 0.12, 0.02], (N, 3)).astype(np.float32)
+    roll, pitch, yaw, t = po.sample_random_stress_poses(rng, B)
+    uv = np.stack([po.project(P.astype(np.float64), K, po.euler_to_R(roll[i], yaw[i], pitch[i], True), t[i], True)
+                   for i in range(B)]).astype(np.float32)
+    out = solve_dev(uv, P, torch_dev)
+    ref = c_oracle.qeif_batch(uv.astype(np.float64), P.astype(np.float64), K)
+    assert np.array_equal(out["iters"], ref["iters"])
+    assert_tight(out, ref)
+    if N * 20 * 4 <= 64 * 1024:         # per-problem patterns must still fit LDS at 64 lanes per problem
+        own = solve_dev(uv, np.broadcast_to(P, (B, N, 3)), torch_dev)
+        assert_tight(own, ref)
+    d = solve_dev(uv, P, torch_dev, method="dlt")
+    refd = c_oracle.dlt_batch(uv.astype(np.float64), P.astype(np.float64), K)
+    clear = np.isfinite(refd["R"]).all(axis=(1, 2)) & (refd["margins"][:, 0] > 1e-7) & (refd["margins"][:, 1] > 1e-7)
+    if N >= 6:                          # fewer points leave the 4x4 system close to singular
+        assert clear.sum() > 0.9 * B
+        assert_tight(d, refd, clear)
+
+
+def test_point_count_limits(torch_dev):
+    lib = _lib.load()
+    nmax = lib.pnp_max_points()
+    with pytest.raises(_lib.PnpError):
+        pnp.solve_pnp_batch(np.zeros((2, nmax + 1, 2), np.float32), np.zeros((nmax + 1, 3), np.float32), K)
+    for N in (1, 2, 3):                 # under-determined: runs, returns non-finite or arbitrary poses
+        out = pnp.solve_pnp_batch(np.ones((3, N, 2), np.float32), np.ones((N, 3), np.float32), K)
+        assert out["R"].shape == (3, 3, 3)
+
+
+def test_unaligned_and_strided_device_buffers(golden, torch_dev):
+    """Sub-tensor views: base pointers only 4-byte aligned, and a pattern stride wider than 3N."""
+    import torch
+    g, uv = stress_uv6(golden)
+    B = 700
+    lib = _lib.load()
+    ref = solve_dev(uv[:B], P6f, torch_dev)
+    flat = torch.zeros(B * 12 + 3, device=torch_dev)
+    flat[3:] = to_dev(uv[:B], torch_dev).reshape(-1)
+    wide = torch.zeros((B, 25), device=torch_dev)
+    wide[:, :18] = to_dev(np.broadcast_to(P6f, (B, 6, 3)), torch_dev).reshape(B, 18)
+    R = torch.empty((B, 9), device=torch_dev)
+    t = torch.empty((B, 3), device=torch_dev)
+    for entry in ("qeif", "dlt"):
+        if entry == "qeif":
+            rc = lib.pnp_qeif_batch_f32(flat[3:].data_ptr(), wide.data_ptr(), 25, _lib.k_array(K), B, 6, None,
+                                        R.data_ptr(), t.data_ptr(), None, None, None, _lib.PTR_DEVICE,
+                                        torch.cuda.current_stream().cuda_stream)
+            want = ref
+        else:
+            rc = lib.pnp_dlt_batch_f32(flat[3:].data_ptr(), wide.data_ptr(), 25, _lib.k_array(K), B, 6, 3,
+                                       R.data_ptr(), t.data_ptr(), None, None, _lib.PTR_DEVICE,
+                                       torch.cuda.current_stream().cuda_stream)
+            want = solve_dev(uv[:B], P6f, torch_dev, method="dlt")
+        _lib.check(rc)
+        torch.cuda.synchronize()
+        assert np.array_equal(R.cpu().numpy().reshape(B, 3, 3), want["R"], equal_nan=True)
+        assert np.array_equal(t.cpu().numpy(), want["t"], equal_nan=True)
+
+
+def test_non_default_stream(golden, torch_dev):
+    import torch
+    g, uv = stress_uv6(golden)
+    base = solve_dev(uv[:2048], P6f, torch_dev)
+    s = torch.cuda.Stream(device=torch_dev)
+    uv_d, P_d = to_dev(uv[:2048], torch_dev), to_dev(P6f, torch_dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        out = pnp.solve_pnp_batch(uv_d, P_d, K)
+    s.synchronize()
+    assert np.array_equal(out["R"].cpu().numpy(), base["R"])
+
+
+def test_general_camera_matrix(torch_dev):
+    """K with skew and unequal focal lengths: the full first two rows of K^-1 are used."""
+    Kg = np.array([[310.0, 1.5, 158.0], [0.0, 295.0, 121.5], [0.0, 0.0, 1.0]])
+    rng = np.random.default_rng(9)
+    B = 500
+    roll, pitch, yaw, t = po.sample_random_stress_poses(rng, B)
+    uv = np.stack([po.project(P6f.astype(np.float64), Kg, po.euler_to_R(roll[i], yaw[i], pitch[i], True), t[i], True)
+                   for i in range(B)]).astype(np.float32)
+    out = to_np(pnp.solve_pnp_batch(to_dev(uv, torch_dev), to_dev(P6f, torch_dev), Kg))
+    ref = c_oracle.qeif_batch(uv.astype(np.float64), P6f.astype(np.float64), Kg)
+    assert np.array_equal(out["iters"], ref["iters"])
+    assert_tight(out, ref)
+
+
+# ---------------------------------------------------------------------------------------------
+# the drop-in class (reference call signature)
+# ---------------------------------------------------------------------------------------------
+
+def img_dict(uv, keys):
+    return {k: np.array([[uv[i, 0]], [uv[i, 1]], [1.0]]) for i, k in enumerate(keys)}
+
+
+def test_dropin_solve_pnp_known_pose(golden, torch_dev):
+    """Config 1 of the baseline: the fixed pose of random_stress_test.py:260-270."""
+    g = golden("known_cases")
+    keys15 = [str(k) for k in g["keys15"]]
+    s = pnp.PNP_SOLVER(K, [po.PATTERN_ALEXANDER], pattern_scale_list=[1.0], verbose=False)
+    gt = pnp.PNP_SOLVER(K, [po.PATTERN_ALEXANDER])
+    R_gt = gt.get_rotation_matrix_from_Euler(15.0, 45.0, -15.0, is_degree=True)
+    img = gt.perspective_projection_golden_landmarks(R_gt, np.array([[0.35], [0.35], [0.5]]), is_quantized=True)
+    assert list(img) == keys15
+    R, t, t3, roll, yaw, pitch, res = s.solve_pnp(img)
+    assert R.shape == (3, 3) and R.dtype == np.float64 and t.shape == (3, 1) and t.dtype == np.float64
+    assert all(isinstance(v, np.float64) for v in (t3, roll, yaw, pitch, res))
+    assert rot_angle(R, g["R"])[0] <= ANG_TOL and rel_t(t[:, 0], g["t"])[0] <= RELT_TOL
+    assert abs(roll - g["roll"]) < 1e-3 and abs(yaw - g["yaw"]) < 1e-3 and abs(pitch - g["pitch"]) < 1e-3
+    assert abs(roll - 14.9501) < 1e-3 and abs(yaw - 45.4484) < 1e-3 and abs(pitch + 15.1464) < 1e-3
+    assert abs(res - g["res_norm"]) < 1e-7 and t3 == t[2, 0]
+    assert np.array_equal(s.np_R_c_a_est, R) and np.array_equal(s.np_t_c_a_est, t)
+    assert s.current_golden_pattern_id == 0
+    before = {k: v.copy() for k, v in img.items()}
+    s.solve_pnp(img)
+    assert all(np.array_equal(img[k], before[k]) for k in img)        # inputs are not mutated
+
+
+def test_dropin_stress_loop_matches_reference_run(golden, torch_dev):
+    """First samples of the random-stress run, one solve_pnp call per sample as the driver does."""
+    g = golden("stress_qeif_n6")
+    keys15 = [str(k) for k in g["keys15"]]
+    s = pnp.PNP_SOLVER(K, [po.PATTERN_ALEXANDER], pattern_scale_list=[1.0])
+    for i in range(40):
+        R, t, t3, roll, yaw, pitch, res = s.solve_pnp(img_dict(g["uv15"][i].astype(np.float64), keys15))
+        assert rot_angle(R, g["R"][i])[0] <= ANG_TOL and rel_t(t[:, 0], g["t"][i])[0] <= RELT_TOL
+        assert abs(roll - g["roll"][i]) < 1e-3 and abs(yaw - g["yaw"][i]) < 1e-3 and abs(pitch - g["pitch"][i]) < 1e-3
+
+
+def test_dropin_two_patterns(golden, torch_dev):
+    g = golden("multi_pattern")
+    s = pnp.PNP_SOLVER(K, [po.PATTERN_ALEXANDER, po.PATTERN_HOLLY], pattern_scale_list=[1.0, 1.0])
+    for i in range(30):
+        R, t, *_ = s.solve_pnp(img_dict(g["uv"][i].astype(np.float64), po.LM6_KEYS))
+        assert s.current_golden_pattern_id == g["pattern_id"][i]
+        assert rot_angle(R, g["R"][i])[0] <= ANG_TOL
+    out = s.solve_pnp_batch(g["uv"], all_patterns=True)
+    assert np.array_equal(out["pattern_id"], g["pattern_id"])
+
+
+def test_dropin_named_solvers(golden, torch_dev):
+    s = pnp.PNP_SOLVER(K, [po.PATTERN_ALEXANDER])
+    pat = s.np_point_3d_pretransfer_dict_list[0]
+    g = golden("dlt_n15")
+    keys = [str(k) for k in g["keys"]]
+    ref = c_oracle.dlt_batch(g["uv"][:20].astype(np.float64), P15.astype(np.float32).astype(np.float64), K)
+    for i in range(20):
+        if g["raised"][i] or ref["margins"][i, :2].min() < 1e-7:
+            continue
+        R, t, t3, roll, yaw, pitch, res = s.solve_pnp_single_pattern(img_dict(g["uv"][i].astype(np.float64), keys), pat)
+        assert rot_angle(R, g["R"][i])[0] <= ANG_TOL and abs(res - g["res_norm"][i]) < 1e-6
+    g = golden("qeif_n68")
+    keys68 = ["p%02d" % i for i in range(68)]
+    s68 = pnp.PNP_SOLVER(K, [{k: g["xyz"][i].tolist() for i, k in enumerate(keys68)}])
+    for i in range(10):
+        R, t, *_ = s68.solve_pnp_QEIF_single_pattern(img_dict(g["uv"][i].astype(np.float64), keys68),
+                                                     s68.np_point_3d_pretransfer_dict_list[0], LM_key_list=None)
+        assert rot_angle(R, g["R"][i])[0] <= ANG_TOL and rel_t(t[:, 0], g["t"][i])[0] <= RELT_TOL
+
+
+def test_landmark_noise_sweep_through_batch_api(golden, torch_dev):
+    """Reduced grid of the landmark-noise study: one batched launch per (yaw, sigma) cell."""
+    g = golden("lm_noise_small")
+    idx = [list(po.PATTERN_ALEXANDER).index(k) for k in po.LM6_KEYS]
+    s = pnp.PNP_SOLVER(K, [po.PATTERN_ALEXANDER])
+    yaw_est = np.zeros_like(g["yaw_est"])
+    for yi in range(len(g["yaw_list"])):
+        for si, sigma in enumerate(g["sigma_list"]):
+            pts = (g["uv_clean"][yi][None] + (sigma / 112.0 * 30.0) * g["noise"]).astype(np.float32)
+            yaw_est[yi, si] = s.solve_pnp_batch(pts[:, idx, :])["rpy_deg"][:, 1]
+    assert np.abs(yaw_est - g["yaw_est"]).max() <= 2e-3
+    err = yaw_est - g["yaw_list"][:, None, None]
+    assert np.abs(err.mean(axis=2) - g["mesh_mean"]).max() <= 1e-3
+    assert np.abs(err.std(axis=2) - g["mesh_std"]).max() <= 1e-3
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size batches: properties that do not need a full-size oracle run
+# ---------------------------------------------------------------------------------------------
+
+def test_full_size_batch_properties(golden, torch_dev):
+    """1,048,576 problems (the headline batch): tiling the 10,000 golden problems, every copy of
+    a problem gets bit-identical outputs wherever it sits in the grid, permuting the problems
+    permutes the outputs, rotations are orthonormal with det +1, and a strided sample agrees
+    with the oracle."""
+    import torch
+    g, uv = stress_uv6(golden)
+    B = 1 << 20
+    reps = -(-B // len(uv))
+    big = np.tile(uv, (reps, 1, 1))[:B]
+    xyz = np.broadcast_to(P6f, (B, 6, 3))
+    uv_d, xyz_d = to_dev(big, torch_dev), to_dev(xyz, torch_dev)
+    out = pnp.solve_pnp_batch(uv_d, xyz_d, K)
+    torch.cuda.synchronize()
+    R, t, it = out["R"], out["t"], out["iters"]
+    n = len(uv)
+    first = R[:n]
+    for k in range(1, B // n):
+        assert torch.equal(R[k * n:(k + 1) * n], first)
+    assert torch.equal(it[n:2 * n], it[:n]) and torch.equal(t[n:2 * n], t[:n])
+    perm = torch.randperm(B, device=torch_dev, generator=torch.Generator(device=torch_dev).manual_seed(0))
+    outp = pnp.solve_pnp_batch(uv_d[perm].contiguous(), xyz_d[perm].contiguous(), K)
+    torch.cuda.synchronize()
+    assert torch.equal(outp["R"], R[perm]) and torch.equal(outp["t"], t[perm]) and torch.equal(outp["iters"], it[perm])
+    RtR = torch.bmm(R.transpose(1, 2), R)
+    assert (RtR - torch.eye(3, device=torch_dev)).abs().max().item() < 1e-5
+    assert (torch.linalg.det(R.double()) - 1.0).abs().max().item() < 1e-5
+    assert int(it.min()) >= 1 and int(it.max()) <= 14
+    sample = np.arange(0, B, 997)
+    ref = c_oracle.qeif_batch(big[sample].astype(np.float64), P6f.astype(np.float64), K)
+    got = dict(R=R[sample].cpu().numpy(), t=t[sample].cpu().numpy(), res_norm=out["res_norm"][sample].cpu().numpy())
+    assert np.array_equal(it[sample].cpu().numpy(), ref["iters"])
+    assert_tight(got, ref)
+    d = pnp.solve_pnp_batch(uv_d, xyz_d, K, method="dlt")
+    torch.cuda.synchronize()
+    assert torch.equal(d["R"][n:2 * n], d["R"][:n])
+    refd = c_oracle.dlt_batch(big[sample].astype(np.float64), P6f.astype(np.float64), K)
+    clear = np.isfinite(refd["R"]).all(axis=(1, 2)) & (refd["margins"][:, 0] > 1e-7) & (refd["margins"][:, 1] > 1e-7)
+    gotd = dict(R=d["R"][sample].cpu().numpy(), t=d["t"][sample].cpu().numpy(),
+                res_norm=d["res_norm"][sample].cpu().numpy())
+    assert_tight(gotd, refd, clear)

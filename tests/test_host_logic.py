@@ -1,0 +1,172 @@
+"""Host-side logic that needs no GPU: the C ABI loads and exports what the header declares,
+argument errors are reported before any device work, the drop-in class keeps the reference's
+host-visible behaviour, and the rank sharding is a partition."""
+import copy
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pnp_solver_test_amd as pnp
+from conftest import ROOT, lm6_indices
+from oracle import pnp_oracle as po
+from pnp_solver_test_amd import _lib
+
+K = po.K_DEFAULT
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "pnp_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pnp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = header_functions()
+    assert sorted(_lib.EXPORTS) == declared
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert b"gfx950" in lib.pnp_version()
+    assert lib.pnp_max_points() >= 68
+
+
+def test_default_params_are_the_reference_constants():
+    p = _lib.default_params()
+    assert p.q_inv == (225.68 ** 2) / 9.0 and p.r_quat == 0.1 and p.r_delta == 0.01
+    assert p.omega0 == 1e-5 and p.max_it == 14 and p.rel_tol == 1e-2 and p.res_old0 == 1e-7
+    assert pnp.make_params(max_it=5).max_it == 5
+    with pytest.raises(TypeError):
+        pnp.make_params(bogus=1)
+
+
+def test_argument_errors_come_back_as_codes_with_messages():
+    lib = _lib.load()
+    Kc = _lib.k_array(K)
+    buf = (ctypes.c_float * 64)()
+    a = ctypes.addressof(buf)
+    assert lib.pnp_qeif_batch_f32(a, a, 0, Kc, -1, 6, None, a, a, None, None, None, 0, None) == -1
+    assert b"negative" in lib.pnp_last_error()
+    assert lib.pnp_qeif_batch_f32(a, a, 0, Kc, 1, 0, None, a, a, None, None, None, 0, None) == -1
+    assert lib.pnp_qeif_batch_f32(a, a, 0, Kc, 1, 6, None, a, a, None, None, None, 7, None) == -1
+    assert lib.pnp_qeif_batch_f32(None, a, 0, Kc, 1, 6, None, a, a, None, None, None, 0, None) == -1
+    assert lib.pnp_qeif_batch_f32(a, a, 5, Kc, 1, 6, None, a, a, None, None, None, 0, None) == -1
+    assert lib.pnp_dlt_batch_f32(a, a, 0, Kc, 1, 6, 0, a, a, None, None, 0, None) == -1
+    singular = _lib.k_array(np.zeros((3, 3)))
+    assert lib.pnp_qeif_batch_f32(a, a, 0, singular, 1, 6, None, a, a, None, None, None, 0, None) == -1
+    assert b"singular" in lib.pnp_last_error()
+    assert lib.pnp_set_lanes_per_problem(3) == -1
+    assert lib.pnp_set_lanes_per_problem(0) == 0
+    # an empty batch is a no-op, not an error, and touches no device
+    assert lib.pnp_qeif_batch_f32(None, None, 0, Kc, 0, 6, None, None, None, None, None, None, 0, None) == 0
+    assert lib.pnp_euler_deg_f32(None, 0, None, 0, None) == 0
+
+
+def test_lanes_per_problem_heuristic():
+    lib = _lib.load()
+    lib.pnp_set_lanes_per_problem(0)
+    assert lib.pnp_get_lanes_per_problem(1 << 20, 6, 18) == 1      # a lane per problem
+    assert lib.pnp_get_lanes_per_problem(1 << 18, 68, 0) >= 4      # LDS bound for 68 points
+    assert lib.pnp_get_lanes_per_problem(1, 68, 0) == 64           # one wavefront per problem
+    assert lib.pnp_get_lanes_per_problem(1, 6, 0) >= 2
+
+
+def test_python_argument_checks():
+    with pytest.raises(ValueError):
+        pnp.solve_pnp_batch(np.zeros((4, 6, 3), np.float32), np.zeros((6, 3), np.float32), K)
+    with pytest.raises(ValueError):
+        pnp.solve_pnp_batch(np.zeros((4, 6, 2), np.float32), np.zeros((5, 3), np.float32), K)
+    with pytest.raises(ValueError):
+        pnp.solve_pnp_batch(np.zeros((4, 6, 2), np.float32), np.zeros((6, 3), np.float32), K, method="lm")
+
+
+def make_solver(patterns=None, **kw):
+    patterns = [po.PATTERN_ALEXANDER] if patterns is None else patterns
+    return pnp.PNP_SOLVER(K, patterns, **kw)
+
+
+def test_constructor_semantics():
+    pat = {k: list(v) for k, v in po.PATTERN_ALEXANDER.items()}
+    Kin = K.copy()
+    s = pnp.PNP_SOLVER(Kin, [pat, pat], pattern_scale_list=[0.5])
+    assert s.pattern_scale_list == [0.5, 1.0]                      # padded with 1.0
+    pat["eye_l_96"][0] = 9.0
+    Kin[0, 0] = 1.0                                                # inputs were deep-copied
+    assert s.point_3d_dict_list[0]["eye_l_96"][0] == 0.032 and s.np_K_camera_est[0, 0] == po.F_CAMERA
+    assert s.np_point_3d_dict_list[0]["eye_l_96"].shape == (3, 1)
+    assert s.np_point_3d_dict_list[0]["eye_l_96"][0, 0] == 0.016
+    assert s.current_golden_pattern_id == 0 and s.verbose is False
+    assert np.array_equal(s.np_R_c_a_est, np.eye(3)) and s.np_t_c_a_est.shape == (3, 1)
+    s2 = copy.deepcopy(s)                                          # face_variation_test.py:933
+    s2.update_the_selected_golden_pattern(0, po.PATTERN_HOLLY, 1.0)
+    assert s2.np_point_3d_dict_list[0]["eye_l_96"][0, 0] == 0.028
+    assert s.np_point_3d_dict_list[0]["eye_l_96"][0, 0] == 0.016
+
+
+def test_missing_landmark_raises_keyerror_before_any_device_work():
+    s = make_solver()
+    img = {k: np.array([[1.0], [2.0], [1.0]]) for k in po.LM6_KEYS[:-1]}
+    with pytest.raises(KeyError):
+        s.solve_pnp(img)
+
+
+def test_euler_and_projection_helpers_match_reference(golden):
+    g = golden("known_cases")
+    s = make_solver()
+    for ang, R, out in zip(g["euler_in"], g["euler_R"], g["euler_out"]):
+        assert np.array_equal(s.get_rotation_matrix_from_Euler(*ang, is_degree=True), R)
+        assert np.array_equal(np.array(s.get_Euler_from_rotation_matrix(R, verbose=False, is_degree=True)), out)
+    rad = s.get_Euler_from_rotation_matrix(g["euler_R"][0])
+    assert np.allclose(np.rad2deg(rad), g["euler_out"][0])
+    img = s.perspective_projection_golden_landmarks(g["R_gt"], g["t_gt"].reshape(3, 1), is_quantized=True)
+    assert list(img.keys()) == [str(k) for k in g["keys15"]]
+    assert img["eye_l_96"].shape == (3, 1) and img["eye_l_96"][2, 0] == 1.0
+    uv = np.array([[img[k][0, 0], img[k][1, 0]] for k in img])
+    assert np.array_equal(uv, g["uv15"])
+    flat = s.perspective_projection_golden_landmarks(g["R_gt"], g["t_gt"].reshape(3, 1),
+                                                     is_returning_homogeneous_vec=False)
+    assert flat["eye_l_96"].shape == (2,)
+    uv_o, dx, dy, dz = s.perspective_projection_obj_axis(g["R_gt"], g["t_gt"].reshape(3, 1), scale=0.1)
+    assert uv_o.shape == dx.shape == dy.shape == dz.shape == (2,)
+    assert np.allclose(s.unit_vec(np.array([3.0, 4.0])), [0.6, 0.8])
+    assert np.allclose(s.unit_vec(np.zeros(3)), 0.0)
+
+
+def test_dict_to_array_glue(golden):
+    g = golden("known_cases")
+    s = make_solver()
+    keys15 = [str(k) for k in g["keys15"]]
+    img = {k: np.array([[g["uv15"][i, 0]], [g["uv15"][i, 1]], [1.0]]) for i, k in enumerate(keys15)}
+    uv = s._image_array(img, pnp.LM_KEY_LIST)
+    assert uv.dtype == np.float32 and uv.shape == (1, 6, 2)
+    assert np.array_equal(uv[0], g["uv15"][lm6_indices(g)])
+    P = s._pattern_array(s.np_point_3d_pretransfer_dict_list[0], pnp.LM_KEY_LIST)
+    assert np.array_equal(P, po.pattern_array(po.PATTERN_ALEXANDER, po.LM6_KEYS).astype(np.float32))
+
+
+def test_dropin_module_is_importable_by_its_reference_name():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("PNP_SOLVER_LIB", os.path.join(ROOT, "dropin", "PNP_SOLVER_LIB.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.PNP_SOLVER is pnp.PNP_SOLVER
+    # every attribute the reference's drivers touch
+    for name in ("solve_pnp", "get_rotation_matrix_from_Euler", "get_Euler_from_rotation_matrix",
+                 "set_golden_pattern_id", "perspective_projection_golden_landmarks",
+                 "perspective_projection_obj_axis", "update_the_selected_golden_pattern", "unit_vec",
+                 "solve_pnp_single_pattern", "solve_pnp_QEIF_single_pattern", "lib_print"):
+        assert callable(getattr(mod.PNP_SOLVER, name))
+
+
+def test_shard_bounds_partition():
+    for total, world in ((8 << 20, 8), (10, 3), (5, 8), (0, 4), (1 << 20, 1)):
+        spans = [pnp.shard_bounds(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert pnp.shard_bounds(8 << 20, 3, 8) == (3 << 20, 4 << 20)
+    with pytest.raises(ValueError):
+        pnp.shard_bounds(10, 4, 4)
