@@ -3,11 +3,21 @@
 The library is built in-tree by pnp_solver_test_amd/csrc/Makefile.  There is no CPU
 fallback: if the shared object is missing or cannot be loaded, importing the solver fails
 with an explicit error.
+
+One process, one HIP runtime.  The PyTorch-ROCm wheel bundles its own libamdhip64.so.7 /
+libhsa-runtime64.so; a process that brings up both that copy and /opt/rocm's ends up with two
+runtimes, and the one initialised second sees no device.  libpnp_hip.so links the runtime by
+soname only, so the copy already resident wins: when torch is installed it is therefore
+imported BEFORE the library is opened, and both then share torch's runtime (and device
+pointers, streams and events are interchangeable).  Without torch the library uses the
+system runtime.  Set PNP_HIP_NO_TORCH=1 to skip the import.
 """
 from __future__ import annotations
 
 import ctypes
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpnp_hip.so")
@@ -48,6 +58,9 @@ def load():
         raise ImportError(
             "%s not found: build it with `make -C pnp_solver_test_amd/csrc` (or "
             "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH)
+    if ("torch" not in sys.modules and not os.environ.get("PNP_HIP_NO_TORCH")
+            and importlib.util.find_spec("torch") is not None):
+        import torch  # noqa: F401  (see module docstring: share torch's HIP runtime)
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     pp = ctypes.POINTER(QeifParams)

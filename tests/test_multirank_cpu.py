@@ -1,0 +1,62 @@
+"""The multi-rank path on CPU (gloo, world_size 2): per-rank contiguous slices tile the batch
+and the optional result gather restores rank order.  The solver itself needs a GPU, so each
+rank's "solve" here is the C oracle on its slice; what is under test is the sharding and the
+collective, which are the same code on RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import lm6_indices, load_golden
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pnp_solver_test_amd as pnp
+        from oracle import c_oracle, pnp_oracle as po
+        g = load_golden("stress_qeif_n6")
+        uv = g["uv15"][:total, lm6_indices(g), :].astype(np.float64)
+        P6 = po.pattern_array(po.PATTERN_ALEXANDER, po.LM6_KEYS)
+        lo, hi = pnp.shard_bounds(total, rank, world)
+        r = c_oracle.qeif_batch(uv[lo:hi], P6, po.K_DEFAULT)
+        local = dict(R=torch.from_numpy(r["R"].astype(np.float32)), t=torch.from_numpy(r["t"].astype(np.float32)),
+                     iters=torch.from_numpy(r["iters"]))
+        full = pnp.gather_results(local)
+        # whole-job time is the slowest rank's, as bench.py reports it
+        tmax = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        assert tmax.item() == float(world)
+        if rank == 0:
+            np.savez(out_path, R=full["R"].numpy(), t=full["t"].numpy(), iters=full["iters"].numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_slices_and_gather(tmp_path):
+    from oracle import c_oracle, pnp_oracle as po
+    total, world = 2000, 2
+    out_path = str(tmp_path / "gathered.npz")
+    mp.spawn(_worker, args=(world, _free_port(), total, out_path), nprocs=world, join=True)
+    got = np.load(out_path)
+    g = load_golden("stress_qeif_n6")
+    uv = g["uv15"][:total, lm6_indices(g), :].astype(np.float64)
+    ref = c_oracle.qeif_batch(uv, po.pattern_array(po.PATTERN_ALEXANDER, po.LM6_KEYS), po.K_DEFAULT)
+    assert got["R"].shape == (total, 3, 3)
+    assert np.array_equal(got["R"], ref["R"].astype(np.float32))
+    assert np.array_equal(got["t"], ref["t"].astype(np.float32))
+    assert np.array_equal(got["iters"], ref["iters"])
