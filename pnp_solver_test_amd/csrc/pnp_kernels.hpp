@@ -103,6 +103,39 @@ __device__ __forceinline__ void spd_inverse(double (&a)[n * (n + 1) / 2])
     }
 }
 
+// In-place symmetric sweep of every pivot: a <- -(a^-1) for a symmetric definite n x n
+// matrix held as its packed lower triangle.  Sweeping pivot k maps
+//   a_kk -> -1/a_kk,  a_ik -> a_ik/a_kk,  a_ij -> a_ij - a_ik a_jk / a_kk   (i, j != k)
+// which keeps the matrix symmetric at every step, so the whole inversion runs in the 21
+// registers of the packed triangle plus one column of temporaries.  Works for positive and
+// for negative definite input alike (no pivoting is needed in either case).
+template <int n>
+__device__ __forceinline__ void sweep_neg_inverse(double (&a)[n * (n + 1) / 2])
+{
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+        const double dinv = rcp(a[tri(k, k)]);
+        double t[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+            if (i != k) t[i] = a[i > k ? tri(i, k) : tri(k, i)] * dinv;
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            if (i == k) continue;
+            const double aik = a[i > k ? tri(i, k) : tri(k, i)];
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                if (j == k) continue;
+                a[tri(i, j)] = __builtin_fma(-aik, t[j], a[tri(i, j)]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+            if (i != k) a[i > k ? tri(i, k) : tri(k, i)] = t[i];
+        a[tri(k, k)] = -dinv;
+    }
+}
+
 // Solves M x = b1 and M x = b2 for a packed SPD n x n matrix (LDL^T, two right-hand sides).
 template <int n>
 __device__ __forceinline__ void spd_solve2(const double (&m)[n * (n + 1) / 2], double (&b1)[n],
@@ -204,30 +237,33 @@ __device__ __forceinline__ void stage_floats(float *dst, const float *src, int c
 // QEIF: quaternion iterated information filter (damped Gauss-Newton on [q, delta1, delta2])
 // ------------------------------------------------------------------------------------------
 
-// Partial normal-equation sums of one lane.  With H_x = [u, 1, 0], H_y = [v, 0, 1] (u, v the
-// 4-vectors of quaternion derivatives) the information matrix A = sum H^T H has the blocks
-// qq[10] = sum(u u^T + v v^T), q4[4] = sum u, q5[4] = sum v, A44 = A55 = N, A45 = 0, and the
-// gradient is g = sum(H_x^T r_x + H_y^T r_y).
-struct QeifSums {
-    double qq[10], q4[4], q5[4], g[6], ss;
-};
-
-__device__ __forceinline__ void qeif_point(QeifSums &a, const double (&phi)[9], double qa,
-                                           double qb, double qc, double qd, double d1, double d2,
-                                           double X, double Y, double Z, double bx, double by)
+// One point's contribution to the information matrix, the gradient and the squared residual.
+//
+// Everything is carried in units scaled by c = sqrt(q_inv), so that the products land in the
+// information matrix Omega = Obar + q_inv H^T H without a separate scaling pass:
+//   qs[4] = c * 2q,  hq[4] = q / 2
+//   s~ = c * s with  p^T Q1 = [s0 s1 s2 s3], p^T Q2 = [-s3 -s2 s1 s0], p^T Q3 = [s2 -s3 -s0 s1]
+//        (the three 3x4 Jacobians d(phi_j)/dq share these four products of the point with 2q)
+//   c * P phi_j = (p^T Q_j) . q / 2           (phi_j is a quadratic form in q)
+//   u~ = c (p^T Q1 - bx p^T Q3), v~ = c (p^T Q2 - by p^T Q3): rows H_x = [u, 1, 0], H_y = [v, 0, 1]
+//   r~ = c (z - h)
+// M receives q_inv H^T H in its (q,q), (d1,q) and (d2,q) entries (packed lower 6x6; the
+// constant (d,d) block q_inv*N*I is added by the caller); g receives [c^2 H_q^T r, c r_x, c r_y]
+// summed, ss the sum of c^2 r^2.
+__device__ __forceinline__ void qeif_point(double (&M)[21], double (&g)[6], double &ss,
+                                           const double (&qs)[4], const double (&hq)[4], double c,
+                                           double d1, double d2, double X, double Y, double Z,
+                                           double bx, double by)
 {
-    // residual of the measurement model  h = [P phi1 - bx P phi3 + d1 ; P phi2 - by P phi3 + d2]
-    const double p1 = __builtin_fma(X, phi[0], __builtin_fma(Y, phi[1], Z * phi[2]));
-    const double p2 = __builtin_fma(X, phi[3], __builtin_fma(Y, phi[4], Z * phi[5]));
-    const double p3 = __builtin_fma(X, phi[6], __builtin_fma(Y, phi[7], Z * phi[8]));
-    const double rx = bx - (__builtin_fma(-bx, p3, p1) + d1);
-    const double ry = by - (__builtin_fma(-by, p3, p2) + d2);
-    // p^T Q1 = [s0 s1 s2 s3], p^T Q2 = [-s3 -s2 s1 s0], p^T Q3 = [s2 -s3 -s0 s1]
-    // with (qa,qb,qc,qd) = 2(qr,qi,qj,qk): the three 3x4 Jacobians share four products.
-    const double s0 = __builtin_fma(X, qa, __builtin_fma(-Y, qd, Z * qc));
-    const double s1 = __builtin_fma(X, qb, __builtin_fma(Y, qc, Z * qd));
-    const double s2 = __builtin_fma(-X, qc, __builtin_fma(Y, qb, Z * qa));
-    const double s3 = __builtin_fma(-X, qd, __builtin_fma(-Y, qa, Z * qb));
+    const double s0 = __builtin_fma(X, qs[0], __builtin_fma(-Y, qs[3], Z * qs[2]));
+    const double s1 = __builtin_fma(X, qs[1], __builtin_fma(Y, qs[2], Z * qs[3]));
+    const double s2 = __builtin_fma(-X, qs[2], __builtin_fma(Y, qs[1], Z * qs[0]));
+    const double s3 = __builtin_fma(-X, qs[3], __builtin_fma(-Y, qs[0], Z * qs[1]));
+    const double p1 = __builtin_fma(s0, hq[0], __builtin_fma(s1, hq[1], __builtin_fma(s2, hq[2], s3 * hq[3])));
+    const double p2 = __builtin_fma(-s3, hq[0], __builtin_fma(-s2, hq[1], __builtin_fma(s1, hq[2], s0 * hq[3])));
+    const double p3 = __builtin_fma(s2, hq[0], __builtin_fma(-s3, hq[1], __builtin_fma(-s0, hq[2], s1 * hq[3])));
+    const double rx = __builtin_fma(c, bx - d1, -__builtin_fma(-bx, p3, p1));
+    const double ry = __builtin_fma(c, by - d2, -__builtin_fma(-by, p3, p2));
     double u[4], v[4];
     u[0] = __builtin_fma(-bx, s2, s0);
     u[1] = __builtin_fma(bx, s3, s1);
@@ -241,14 +277,14 @@ __device__ __forceinline__ void qeif_point(QeifSums &a, const double (&phi)[9], 
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int j = 0; j <= i; ++j)
-            a.qq[tri(i, j)] = __builtin_fma(u[i], u[j], __builtin_fma(v[i], v[j], a.qq[tri(i, j)]));
-        a.q4[i] += u[i];
-        a.q5[i] += v[i];
-        a.g[i] = __builtin_fma(u[i], rx, __builtin_fma(v[i], ry, a.g[i]));
+            M[tri(i, j)] = __builtin_fma(u[i], u[j], __builtin_fma(v[i], v[j], M[tri(i, j)]));
+        M[tri(4, i)] = __builtin_fma(c, u[i], M[tri(4, i)]);
+        M[tri(5, i)] = __builtin_fma(c, v[i], M[tri(5, i)]);
+        g[i] = __builtin_fma(u[i], rx, __builtin_fma(v[i], ry, g[i]));
     }
-    a.g[4] += rx;
-    a.g[5] += ry;
-    a.ss = __builtin_fma(rx, rx, __builtin_fma(ry, ry, a.ss));
+    g[4] += rx;
+    g[5] += ry;
+    ss = __builtin_fma(rx, rx, __builtin_fma(ry, ry, ss));
 }
 
 // Gamma(q) = |q|^2 R(q), row-major, and gamma = |q|^2
@@ -275,105 +311,106 @@ __device__ __forceinline__ void gamma_matrix(const double (&x)[6], double (&phi)
 //
 // Recurrence (exact restatement of the information-filter loop, rearranged):
 //   Sigma_0 = I/omega0, x_0 = [1,0,0,0,0,0]
-//   each iteration:  Obar = (Sigma + R_p)^-1
-//                    Omega = Obar + q_inv * A(x)           A, g, ss from the points
-//                    res   = sqrt(ss)                      (residual at the current x)
-//                    Sigma = Omega^-1 ;  x += Sigma * (q_inv * g)
-//                    stop if |res - res_old| / res_old < rel_tol, else res_old = res
+//   each iteration:  Obar = (Sigma + R_p)^-1               (both inverses: symmetric sweeps)
+//                    Omega = Obar + q_inv * H^T H          H, r = z - h at the current x
+//                    res   = |r|                           (residual BEFORE the update)
+//                    Sigma = Omega^-1 ;  x += Sigma * (q_inv * H^T r)
+//                    stop if |res - res_old| < rel_tol * res_old, else res_old = res
 // The reference forms zeta = Obar x + q_inv H^T (z - h + H x) and x = Sigma zeta; since
 // Omega = Obar + q_inv H^T H these are the same vector, x + Sigma q_inv H^T (z - h).
+// Its stopping rule |(res - res_old)/res_old| < rel_tol is the same inequality (res_old > 0).
 template <int LPI, int NCT, typename PointFetch>
 __device__ __forceinline__ void qeif_solve(const PointFetch &pts, int N, int lane_in_group,
                                            const QeifParams &p, double (&R)[9], double (&t)[3],
                                            double &res_out, int &iters_out)
 {
     double x[6] = {1.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    double S[21];  // Sigma, packed lower
+    // T is swept twice per iteration and changes sign each time: it holds -Sigma at the top of
+    // the loop, Obar after the first sweep and -Sigma again after the second.
+    double T[21];
 #pragma unroll
-    for (int i = 0; i < 21; ++i) S[i] = 0.0;
+    for (int i = 0; i < 21; ++i) T[i] = 0.0;
     {
-        const double s0 = 1.0 / p.omega0;
+        const double s0 = -1.0 / p.omega0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) S[tri(i, i)] = s0;
+        for (int i = 0; i < 6; ++i) T[tri(i, i)] = s0;
     }
+    const double c = sqrt(p.q_inv);
+    const double c_inv = 1.0 / c;
+    const double dd = p.q_inv * static_cast<double>(N);
     double res_old = p.res_old0, res = 1.0e5;
-    const double nn = static_cast<double>(N);
     int k = 0;
     while (k < p.max_it) {
         ++k;
-        // predict
+        // predict: -(Sigma + R_p), then sweep -> (Sigma + R_p)^-1 = Obar
 #pragma unroll
-        for (int i = 0; i < 4; ++i) S[tri(i, i)] += p.r_quat;
-        S[tri(4, 4)] += p.r_delta;
-        S[tri(5, 5)] += p.r_delta;
-        spd_inverse<6>(S);  // S now holds Obar
-        // model sums
-        double phi[9], gamma;
-        gamma_matrix(x, phi, gamma);
-        const double qa = 2.0 * x[0], qb = 2.0 * x[1], qc = 2.0 * x[2], qd = 2.0 * x[3];
-        QeifSums a;
+        for (int i = 0; i < 4; ++i) T[tri(i, i)] -= p.r_quat;
+        T[tri(4, 4)] -= p.r_delta;
+        T[tri(5, 5)] -= p.r_delta;
+        sweep_neg_inverse<6>(T);
+        // update: Omega = Obar + q_inv H^T H, accumulated point by point
+        const double qs[4] = {2.0 * c * x[0], 2.0 * c * x[1], 2.0 * c * x[2], 2.0 * c * x[3]};
+        const double hq[4] = {0.5 * x[0], 0.5 * x[1], 0.5 * x[2], 0.5 * x[3]};
+        double g[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double ss = 0.0;
+        if constexpr (LPI == 1) {
+            if constexpr (NCT > 0) {  // the lane owns all NCT points, held in registers
 #pragma unroll
-        for (int i = 0; i < 10; ++i) a.qq[i] = 0.0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a.q4[i] = a.q5[i] = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) a.g[i] = 0.0;
-        a.ss = 0.0;
-        if constexpr (NCT > 0) {  // LPI == 1: the lane owns all NCT points, held in registers
-#pragma unroll
-            for (int i = 0; i < NCT; ++i) {
-                double X, Y, Z, bx, by;
-                pts(i, X, Y, Z, bx, by);
-                qeif_point(a, phi, qa, qb, qc, qd, x[4], x[5], X, Y, Z, bx, by);
+                for (int i = 0; i < NCT; ++i) {
+                    double X, Y, Z, bx, by;
+                    pts(i, X, Y, Z, bx, by);
+                    qeif_point(T, g, ss, qs, hq, c, x[4], x[5], X, Y, Z, bx, by);
+                }
+            } else {
+                for (int i = 0; i < N; ++i) {
+                    double X, Y, Z, bx, by;
+                    pts(i, X, Y, Z, bx, by);
+                    qeif_point(T, g, ss, qs, hq, c, x[4], x[5], X, Y, Z, bx, by);
+                }
             }
         } else {
+            double M[21];  // this lane's share; only the (q,q), (d1,q), (d2,q) entries are used
+#pragma unroll
+            for (int i = 0; i < 21; ++i) M[i] = 0.0;
             for (int i = lane_in_group; i < N; i += LPI) {
                 double X, Y, Z, bx, by;
                 pts(i, X, Y, Z, bx, by);
-                qeif_point(a, phi, qa, qb, qc, qd, x[4], x[5], X, Y, Z, bx, by);
+                qeif_point(M, g, ss, qs, hq, c, x[4], x[5], X, Y, Z, bx, by);
             }
-        }
-        if (LPI > 1) {
-#pragma unroll
-            for (int i = 0; i < 10; ++i) a.qq[i] = group_sum<LPI>(a.qq[i]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                a.q4[i] = group_sum<LPI>(a.q4[i]);
-                a.q5[i] = group_sum<LPI>(a.q5[i]);
+#pragma unroll
+                for (int j = 0; j <= i; ++j) T[tri(i, j)] += group_sum<LPI>(M[tri(i, j)]);
+                T[tri(4, i)] += group_sum<LPI>(M[tri(4, i)]);
+                T[tri(5, i)] += group_sum<LPI>(M[tri(5, i)]);
             }
 #pragma unroll
-            for (int i = 0; i < 6; ++i) a.g[i] = group_sum<LPI>(a.g[i]);
-            a.ss = group_sum<LPI>(a.ss);
+            for (int i = 0; i < 6; ++i) g[i] = group_sum<LPI>(g[i]);
+            ss = group_sum<LPI>(ss);
         }
-        // update: Omega = Obar + q_inv A
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int j = 0; j <= i; ++j) S[tri(i, j)] = __builtin_fma(p.q_inv, a.qq[tri(i, j)], S[tri(i, j)]);
-            S[tri(4, i)] = __builtin_fma(p.q_inv, a.q4[i], S[tri(4, i)]);
-            S[tri(5, i)] = __builtin_fma(p.q_inv, a.q5[i], S[tri(5, i)]);
-        }
-        S[tri(4, 4)] = __builtin_fma(p.q_inv, nn, S[tri(4, 4)]);
-        S[tri(5, 5)] = __builtin_fma(p.q_inv, nn, S[tri(5, 5)]);
-        res = sqrt(a.ss);
-        spd_inverse<6>(S);  // S now holds Sigma
+        T[tri(4, 4)] += dd;
+        T[tri(5, 5)] += dd;
+        g[4] *= c;
+        g[5] *= c;
+        res = sqrt(ss) * c_inv;
+        sweep_neg_inverse<6>(T);  // T = -Sigma
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             double dx = 0.0;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) dx = __builtin_fma(S[i >= j ? tri(i, j) : tri(j, i)], a.g[j], dx);
-            x[i] = __builtin_fma(p.q_inv, dx, x[i]);
+            for (int j = 0; j < 6; ++j) dx = __builtin_fma(T[i >= j ? tri(i, j) : tri(j, i)], g[j], dx);
+            x[i] -= dx;
         }
-        const double ratio = (res - res_old) / res_old;
+        const bool stop = fabs(res - res_old) < p.rel_tol * res_old;
         res_old = res;
-        if (fabs(ratio) < p.rel_tol) break;
+        if (stop) break;
     }
     // reconstruct: R = Gamma(q)/gamma, t3 = 1/gamma, t = [d1, d2, 1] t3
     double phi[9], gamma;
     gamma_matrix(x, phi, gamma);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) R[i] = phi[i] / gamma;
     const double t3 = 1.0 / gamma;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = phi[i] * t3;
     t[0] = x[4] * t3;
     t[1] = x[5] * t3;
     t[2] = t3;
@@ -633,7 +670,7 @@ __device__ __forceinline__ void store_rpy(int64_t problem, const double (&R)[9],
 // each pattern in turn and keeps the first one with the strictly smallest residual.
 // NCT > 0 requires LPI == 1 and N == NCT.
 template <int LPI, int NCT>
-__global__ __launch_bounds__(kBlock) void qeif_kernel(
+__global__ __launch_bounds__(kBlock, 2) void qeif_kernel(
     const float *__restrict__ uv, const float *__restrict__ xyz, int64_t xyz_stride, int n_patterns,
     KinvRows ki, int64_t B, int N, QeifParams p, float *__restrict__ R_out,
     float *__restrict__ t_out, float *__restrict__ res_out, int32_t *__restrict__ iters_out,
