@@ -20,7 +20,8 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpnp_hip.so")
+#: PNP_HIP_LIB selects another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("PNP_HIP_LIB") or os.path.join(_HERE, "libpnp_hip.so")
 
 PTR_HOST = 0
 PTR_DEVICE = 1

@@ -23,6 +23,10 @@ namespace pnp {
 
 constexpr int kBlock = 256;
 
+#ifndef PNP_QEIF_WAVES
+#define PNP_QEIF_WAVES 2  // minimum resident waves per SIMD the QEIF kernels are compiled for
+#endif
+
 struct KinvRows {  // first two rows of K^-1: nu_x = a00 u + a01 v + a02, nu_y = a10 u + a11 v + a12
     double a00, a01, a02, a10, a11, a12;
 };
@@ -46,6 +50,21 @@ __device__ __forceinline__ double rcp(double d)
     e = __builtin_fma(-d, r, 1.0);
     r = __builtin_fma(e, r, r);
     return r;
+}
+
+// sqrt(x) for 0 <= x in the normal range: hardware reciprocal-square-root seed, one coupled
+// Goldschmidt step and one residual correction (error of a few 1e-16 relative).  x == 0 gives
+// 0, x < 0 or NaN gives NaN; no rescaling of subnormal or huge arguments (not met here).
+__device__ __forceinline__ double sqrt_pos(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return (x == 0.0) ? 0.0 : g;
 }
 
 __device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // i >= j
@@ -428,36 +447,37 @@ __device__ __forceinline__ void qeif_solve(const PointFetch &pts, int N, int lan
 // c = det K / gamma, alpha = -c delta, overall sign from the dot product of alpha with the
 // least-squares third column.
 __device__ __forceinline__ void dlt_block_reconstruct(const double (&f)[8], double (&R)[9],
-                                                      double (&t)[3], double &t3)
+                                                      double (&t)[3], double &gamma)
 {
     const double K00 = f[0], K01 = f[1], K10 = f[3], K11 = f[4];
     const double k1 = __builtin_fma(K00, K00, K10 * K10);
     const double k2 = __builtin_fma(K00, K01, K10 * K11);
     const double k3 = __builtin_fma(K01, K01, K11 * K11);
     const double D = __builtin_fma(k1 - k3, k1 - k3, 4.0 * k2 * k2);
-    const double g2 = 0.5 * ((k1 + k3) + sqrt(D));
-    const double g = sqrt(g2);
-    const double e_se = sqrt(g2 - k1);
+    const double g2 = 0.5 * ((k1 + k3) + sqrt_pos(D));
+    const double g = sqrt_pos(g2);
+    const double gi = rcp(g);
+    const double e_se = sqrt_pos(g2 - k1);
     const double sg = (k2 > 0.0) ? 1.0 : ((k2 < 0.0) ? -1.0 : 0.0);
-    const double d_se = -sg * sqrt(g2 - k3);
-    const double det = K00 * K11 - K01 * K10;
-    const double dl0 = (K11 * e_se - K10 * d_se) / det;
-    const double dl1 = (K00 * d_se - K01 * e_se) / det;
-    const double c = det / g;
+    const double d_se = -sg * sqrt_pos(g2 - k3);
+    const double det = __builtin_fma(K00, K11, -(K01 * K10));
+    const double rdet = rcp(det);
+    const double dl0 = __builtin_fma(K11, e_se, -(K10 * d_se)) * rdet;
+    const double dl1 = __builtin_fma(K00, d_se, -(K01 * e_se)) * rdet;
+    const double c = det * gi;
     const double al0 = -(c * dl0), al1 = -(c * dl1);
     const double sim = __builtin_fma(al0, f[2], al1 * f[5]);
-    const double se = (sim < 0.0) ? -1.0 : 1.0;
-    const double gi = 1.0 / g;
+    const double se = (sim < 0.0) ? -gi : gi;  // sign and 1/gamma in one factor
     R[0] = K00 * gi;
     R[1] = K01 * gi;
-    R[2] = se * al0 * gi;
+    R[2] = se * al0;
     R[3] = K10 * gi;
     R[4] = K11 * gi;
-    R[5] = se * al1 * gi;
-    R[6] = se * e_se * gi;
-    R[7] = se * d_se * gi;
+    R[5] = se * al1;
+    R[6] = se * e_se;
+    R[7] = se * d_se;
     R[8] = c * gi;
-    t3 = gi;
+    gamma = g;
     t[0] = f[6] * gi;
     t[1] = f[7] * gi;
     t[2] = gi;
@@ -474,7 +494,7 @@ __device__ __forceinline__ void dlt_solve(const PointFetch &pts, int N, int lane
                                           double &res_out)
 {
     double phi3[3] = {0.0, 0.0, 1.0};
-    double t3 = 0.0, res = 30.0;
+    double gam = 0.0, res = 30.0;  // gam = gamma = 1/t3
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = 0.0;
     t[0] = t[1] = t[2] = 0.0;
@@ -516,12 +536,11 @@ __device__ __forceinline__ void dlt_solve(const PointFetch &pts, int N, int lane
         }
         spd_solve2<4>(M, rx, ry);
         const double f[8] = {rx[0], rx[1], rx[2], ry[0], ry[1], ry[2], rx[3], ry[3]};
-        dlt_block_reconstruct(f, R, t, t3);
+        dlt_block_reconstruct(f, R, t, gam);
         if (it == num_it - 1) {
             // residual of the reconstructed pose against the system just solved
-            const double gi = 1.0 / t3;
-            const double fx[4] = {R[0] * gi, R[1] * gi, R[2] * gi, t[0] * gi};
-            const double fy[4] = {R[3] * gi, R[4] * gi, R[5] * gi, t[1] * gi};
+            const double fx[4] = {R[0] * gam, R[1] * gam, R[2] * gam, t[0] * gam};
+            const double fy[4] = {R[3] * gam, R[4] * gam, R[5] * gam, t[1] * gam};
             double ss = 0.0;
             auto residual = [&](int i) {
                 double X, Y, Z, bx, by;
@@ -540,12 +559,11 @@ __device__ __forceinline__ void dlt_solve(const PointFetch &pts, int N, int lane
                 for (int i = lane_in_group; i < N; i += LPI) residual(i);
             }
             if (LPI > 1) ss = group_sum<LPI>(ss);
-            res = sqrt(ss);
+            res = sqrt_pos(ss);
         }
-        const double gi = 1.0 / t3;
-        phi3[0] = R[6] * gi;
-        phi3[1] = R[7] * gi;
-        phi3[2] = R[8] * gi;
+        phi3[0] = R[6] * gam;  // phi3 = R[2,:] / t3
+        phi3[1] = R[7] * gam;
+        phi3[2] = R[8] * gam;
     }
     res_out = res;
 }
@@ -670,7 +688,7 @@ __device__ __forceinline__ void store_rpy(int64_t problem, const double (&R)[9],
 // each pattern in turn and keeps the first one with the strictly smallest residual.
 // NCT > 0 requires LPI == 1 and N == NCT.
 template <int LPI, int NCT>
-__global__ __launch_bounds__(kBlock, 2) void qeif_kernel(
+__global__ __launch_bounds__(kBlock, PNP_QEIF_WAVES) void qeif_kernel(
     const float *__restrict__ uv, const float *__restrict__ xyz, int64_t xyz_stride, int n_patterns,
     KinvRows ki, int64_t B, int N, QeifParams p, float *__restrict__ R_out,
     float *__restrict__ t_out, float *__restrict__ res_out, int32_t *__restrict__ iters_out,
