@@ -41,10 +41,11 @@ N_POINTS = 6
 
 
 def qeif_flops(n_points, iters_mean):
-    """float64 flops (fma = 2) the kernel executes per solve: per iteration ~75 fused ops per
-    point (model, Jacobian rows, normal-equation sums), two packed 6x6 SPD inversions
-    (~150 each) and ~60 for Gamma(q), the state update and the stopping rule."""
-    return 2.0 * iters_mean * (75.0 * n_points + 2 * 150.0 + 60.0)
+    """float64 flops (fma = 2) the kernel executes per solve: per iteration 78 fused ops per
+    point (shared Jacobian products, model, residual, sums straight into the information
+    matrix), two packed 6x6 symmetric sweeps (150 each) and ~60 for the state update, the
+    residual norm and the stopping rule."""
+    return 2.0 * iters_mean * (78.0 * n_points + 2 * 150.0 + 60.0)
 
 
 def dlt_flops(n_points, num_it=3):

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 --pmc passes of scripts/gpu_pmc.sh (gpurun_out/pmc/*) into
+profiles/<tag>_pmc_summary.json and the per-launch HBM traffic that bench.py reports.
+
+HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (both in KiB): on gfx950 FETCH_SIZE counts
+each 128-byte request of a wide coalesced read as 64 bytes, WRITE_SIZE is exact for streaming
+stores.  The factor is checked here against the known input size of each launch."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", "pmc")
+
+# dispatch order of scripts/pmc_probe.py: 3 launches each
+LAUNCHES = [("qeif_n6_b1m_per_problem_xyz", "qeif_kernel<1, 6>", 1 << 20, 6, True),
+            ("dlt_n6_b1m_per_problem_xyz", "dlt_kernel<1, 6>", 1 << 20, 6, True),
+            ("qeif_n6_b1m_shared_pattern", "qeif_kernel<1, 6>", 1 << 20, 6, False),
+            ("qeif_n68_b256k_shared_pattern", "qeif_kernel<4, 0>", 1 << 18, 68, False)]
+
+
+def load(name):
+    files = glob.glob(os.path.join(src, name, "*counter_collection.csv"))
+    rows = list(csv.DictReader(open(files[0]))) if files else []
+    rows = [r for r in rows if "pnp::" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    return rows
+
+
+def per_launch(name):
+    """{launch label: {counter: mean value}}, dispatches taken in probe order."""
+    rows = load(name)
+    by_disp = collections.OrderedDict()
+    for r in rows:
+        by_disp.setdefault(int(r["Dispatch_Id"]), {"kernel": r["Kernel_Name"]})[r["Counter_Name"]] = float(r["Counter_Value"])
+        by_disp[int(r["Dispatch_Id"])]["dur_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    disp = list(by_disp.values())
+    out = {}
+    for i, (label, kern, B, N, own) in enumerate(LAUNCHES):
+        chunk = disp[3 * i:3 * i + 3]
+        if len(chunk) < 3 or any(kern not in d["kernel"] for d in chunk):
+            continue
+        keys = [k for k in chunk[0] if k != "kernel"]
+        out[label] = {k: sum(d[k] for d in chunk) / len(chunk) for k in keys}
+    return out
+
+
+summary = {}
+for p in ("fetch", "write", "sq1", "sq2", "grbm"):
+    for label, vals in per_launch(p).items():
+        summary.setdefault(label, {}).update({k: v for k, v in vals.items() if k != "dur_ns"})
+        summary[label].setdefault("profiled_kernel_us", {})[p] = round(vals["dur_ns"] / 1e3, 1)
+
+traffic = {}
+for label, kern, B, N, own in LAUNCHES:
+    s = summary.get(label)
+    if not s or "FETCH_SIZE" not in s or "WRITE_SIZE" not in s:
+        continue
+    in_bytes = B * (8 * N + (12 * N if own else 0))
+    s["input_bytes"] = in_bytes
+    s["fetch_bytes_2x"] = 2 * s["FETCH_SIZE"] * 1024
+    s["write_bytes"] = s["WRITE_SIZE"] * 1024
+    s["hbm_bytes_per_launch"] = s["fetch_bytes_2x"] + s["write_bytes"]
+    s["fetch_2x_over_input"] = round(s["fetch_bytes_2x"] / in_bytes, 4)
+    if "SQ_ACTIVE_INST_VALU" in s and "GRBM_GUI_ACTIVE" in s:
+        # SQ_* activity counters tick in quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs
+        s["valu_busy_frac"] = round(4 * s["SQ_ACTIVE_INST_VALU"] / 1024 / (s["GRBM_GUI_ACTIVE"] / 8), 4)
+        s["valu_insts_per_wave"] = round(s["SQ_INSTS_VALU"] / s["SQ_WAVES"], 1)
+    traffic[label + "_bytes_per_launch"] = round(s["hbm_bytes_per_launch"])
+
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+json.dump(summary, open(os.path.join(ROOT, "profiles", tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+traffic["qeif_n6_b1m_bytes_per_launch"] = traffic.get("qeif_n6_b1m_per_problem_xyz_bytes_per_launch")
+traffic["source"] = "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % tag
+json.dump(traffic, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1, sort_keys=True)
+for label, s in summary.items():
+    print(label, {k: s[k] for k in ("hbm_bytes_per_launch", "fetch_2x_over_input", "valu_busy_frac", "valu_insts_per_wave") if k in s})
