@@ -104,6 +104,18 @@ int pnp_qeif_multi_batch_f32(const float *uv, const float *xyz, int32_t n_patter
                              float *rpy_out, int32_t *pattern_id_out, int32_t ptr_kind,
                              void *hip_stream);
 
+/* Synthetic-input generator of the reference's drivers for B poses: replaces
+ * get_rotation_matrix_from_Euler(roll, yaw, pitch, is_degree=True) (PNP_SOLVER_LIB.py:4442-4472)
+ * followed by perspective_projection / perspective_projection_golden_landmarks
+ * (:4532-4557, :4586-4621).  All inputs are float64, as the reference computes them:
+ *   rpy_deg (B,3) roll, yaw, pitch in degrees;  t (B,3);  xyz (N,3) shared (stride 0) or
+ *   (B,N,3) with xyz_problem_stride doubles between problems;  K (3,3) host pointer.
+ *   quantize_q > 0 rounds the pixels half-to-even onto a grid of that step (is_quantized=True),
+ *   quantize_q = 0 leaves them unquantised.   uv_out (B,N,2) float32. */
+int pnp_project_batch_f64(const double *rpy_deg, const double *t, const double *xyz,
+                          int64_t xyz_problem_stride, const double K[9], int64_t B, int32_t N,
+                          double quantize_q, float *uv_out, int32_t ptr_kind, void *hip_stream);
+
 /* How many lanes of a wavefront cooperate on one problem: 1, 2, 4, 8, 16, 32 or 64
  * (64 = one wavefront per problem); 0 restores the automatic choice from (B, N).
  * Process-wide; meant for tuning and tests.  No reference counterpart. */

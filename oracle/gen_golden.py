@@ -95,7 +95,7 @@ def main():
     ap.add_argument('--ref', default='/root/reference/scripts')
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
     ap.add_argument('--n-stress', type=int, default=10000)
-    ap.add_argument('--only', default='', help='comma-separated section numbers (1-8); default all')
+    ap.add_argument('--only', default='', help='comma-separated section numbers (1-9); default all')
     args = ap.parse_args()
     out_dir = os.path.abspath(args.out)
     os.makedirs(out_dir, exist_ok=True)
@@ -311,6 +311,42 @@ def main():
              yaw_list=yaw_list, sigma_list=sigma_list, quantize_q=np.float64(q), uv_clean=uv_clean,
              yaw_est=yaw_est, mesh_mean=err.mean(axis=2), mesh_std=err.std(axis=2),
              mesh_mae=np.abs(err).mean(axis=2))
+
+    # ---- 9. classes and per-class statistics of the stress run, by the reference's toolbox ----
+    if want(9):
+        import contextlib
+        import io
+        import json
+        g = np.load(os.path.join(out_dir, 'stress_qeif_n6.npz'))
+        with contextlib.redirect_stdout(io.StringIO()):          # the toolbox prints its tables
+            cls = TTBX.get_classification_parameters(drpy_class_format='drpy_expand')
+        results = []
+        for i in range(len(g['t3'])):
+            dist_cm = g['t_gt'][i, 2] * 100.0
+            results.append({
+                'class': {'distance': TTBX.classify_drpy(cls, dist_cm, class_name='depth'),
+                          'roll': TTBX.classify_drpy(cls, g['roll_gt'][i], class_name='roll'),
+                          'pitch': TTBX.classify_drpy(cls, g['pitch_gt'][i], class_name='pitch'),
+                          'yaw': TTBX.classify_drpy(cls, g['yaw_gt'][i], class_name='yaw')},
+                't3_est': g['t3'][i], 'distance_GT': dist_cm * 0.01,   # random_stress_test.py:367
+                'roll_est': g['roll'][i], 'roll_GT': g['roll_gt'][i],
+                'pitch_est': g['pitch'][i], 'pitch_GT': g['pitch_gt'][i],
+                'yaw_est': g['yaw'][i], 'yaw_GT': g['yaw_gt'][i]})
+        by_dist = TTBX.get_classified_result(results, class_name='distance', approval_func=None)
+        stats = {}
+        for label, lst in by_dist.items():                       # TEST_TOOLBOX.py:1184-1188
+            kw = dict(class_name='distance', class_label=label, verbose=False)
+            stats[label] = {
+                'depth': TTBX.get_statistic_of_result(lst, data_est_key='t3_est', data_GT_key='distance_GT', unit='cm', unit_scale=100.0, **kw),
+                'roll': TTBX.get_statistic_of_result(lst, data_est_key='roll_est', data_GT_key='roll_GT', unit='deg.', unit_scale=1.0, **kw),
+                'pitch': TTBX.get_statistic_of_result(lst, data_est_key='pitch_est', data_GT_key='pitch_GT', unit='deg.', unit_scale=1.0, **kw),
+                'yaw': TTBX.get_statistic_of_result(lst, data_est_key='yaw_est', data_GT_key='yaw_GT', unit='deg.', unit_scale=1.0, **kw)}
+        doc = {'classes': {k: [r['class'][k] for r in results] for k in ('distance', 'roll', 'pitch', 'yaw')},
+               'stats': {lab: {q: {k: float(v) for k, v in d.items()} for q, d in per.items()} for lab, per in stats.items()}}
+        path = os.path.join(out_dir, 'stress_stats.json')
+        with open(path, 'w') as f:
+            json.dump(doc, f)
+        print('wrote stress_stats.json (%.1f KB)' % (os.path.getsize(path) / 1024.0))
 
     print('done in %.0f s; numpy %s' % (time.time() - t_start, np.__version__))
 

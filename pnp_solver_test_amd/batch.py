@@ -215,3 +215,40 @@ def gather_results(local: dict, group=None) -> dict:
         dist.all_gather_into_tensor(buf, val, group=group)
         out[key] = buf
     return out
+
+
+def project_batch(roll, yaw, pitch, t, xyz, K, quantize_q=0.0, device=None):
+    """Pixels of a pattern under B poses, on the device: the generator half of the reference's
+    drivers (get_rotation_matrix_from_Euler :4442-4472 with angles in degrees, then
+    perspective_projection :4532-4557).  roll, yaw, pitch (B,), t (B,3), xyz (N,3) or (B,N,3),
+    all float64; quantize_q = 1.0 reproduces is_quantized=True.  Returns uv (B,N,2) float32:
+    a NumPy array, or a torch tensor on `device` if one is given."""
+    lib = _lib.load()
+    rpy = np.ascontiguousarray(np.stack([roll, yaw, pitch], axis=1), dtype=np.float64)
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    B = rpy.shape[0]
+    if t.shape != (B, 3):
+        raise ValueError("t must have shape (B, 3)")
+    if xyz.ndim == 2 and xyz.shape[1] == 3:
+        N, stride = xyz.shape[0], 0
+    elif xyz.ndim == 3 and xyz.shape[0] == B and xyz.shape[2] == 3:
+        N, stride = xyz.shape[1], 3 * xyz.shape[1]
+    else:
+        raise ValueError("xyz must have shape (N, 3) or (B, N, 3)")
+    Kc = _lib.k_array(K)
+    if device is None:
+        uv = np.empty((B, N, 2), np.float32)
+        _lib.check(lib.pnp_project_batch_f64(rpy.ctypes.data, t.ctypes.data, xyz.ctypes.data, stride, Kc, B, N,
+                                             float(quantize_q), uv.ctypes.data, _lib.PTR_HOST, None))
+        return uv
+    import torch
+    dev = torch.device(device)
+    with torch.cuda.device(dev):
+        d_rpy, d_t, d_xyz = (torch.from_numpy(a).to(dev) for a in (rpy, t, xyz))
+        uv = torch.empty((B, N, 2), dtype=torch.float32, device=dev)
+        _lib.check(lib.pnp_project_batch_f64(d_rpy.data_ptr(), d_t.data_ptr(), d_xyz.data_ptr(), stride, Kc, B, N,
+                                             float(quantize_q), uv.data_ptr(), _lib.PTR_DEVICE,
+                                             torch.cuda.current_stream(dev).cuda_stream))
+        torch.cuda.current_stream(dev).synchronize()   # the float64 inputs above are temporaries
+    return uv

@@ -438,6 +438,60 @@ int pnp_euler_deg_f32(const float *R, int64_t B, float *rpy, int32_t ptr_kind, v
     return PNP_OK;
 }
 
+int pnp_project_batch_f64(const double *rpy_deg, const double *t, const double *xyz,
+                          int64_t xyz_problem_stride, const double K[9], int64_t B, int32_t N,
+                          double quantize_q, float *uv_out, int32_t ptr_kind, void *hip_stream)
+{
+    g_err[0] = 0;
+    if (B < 0) return fail(PNP_E_ARG, "B = %lld is negative", static_cast<long long>(B));
+    if (N < 1) return fail(PNP_E_ARG, "N = %d must be >= 1", N);
+    if (!K) return fail(PNP_E_ARG, "K is NULL");
+    if (!(quantize_q >= 0.0)) return fail(PNP_E_ARG, "quantize_q must be >= 0");
+    if (ptr_kind != PNP_PTR_HOST && ptr_kind != PNP_PTR_DEVICE)
+        return fail(PNP_E_ARG, "ptr_kind = %d is neither PNP_PTR_HOST nor PNP_PTR_DEVICE", ptr_kind);
+    if (xyz_problem_stride != 0 && xyz_problem_stride < 3 * static_cast<int64_t>(N))
+        return fail(PNP_E_ARG, "xyz_problem_stride = %lld is neither 0 nor >= 3*N",
+                    static_cast<long long>(xyz_problem_stride));
+    if (B == 0) return PNP_OK;
+    if (!rpy_deg || !t || !xyz || !uv_out) return fail(PNP_E_ARG, "rpy_deg, t, xyz and uv_out must not be NULL");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const int64_t nblk = (B + kBlock - 1) / kBlock;
+    if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
+    pnp::Mat3 Km;
+    for (int i = 0; i < 9; ++i) Km.m[i] = K[i];
+    if (ptr_kind == PNP_PTR_DEVICE) {
+        hipLaunchKernelGGL(pnp::project_kernel, dim3(static_cast<unsigned>(nblk)), dim3(kBlock), 0, s, rpy_deg, t,
+                           xyz, xyz_problem_stride, Km, B, N, quantize_q, uv_out);
+        HIP_TRY(hipGetLastError());
+        return PNP_OK;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(PNP_E_HIP, "device index %d out of range", dev);
+    Staging &st = g_staging[dev];
+    std::lock_guard<std::mutex> lock(st.mu);
+    const size_t nB = static_cast<size_t>(B);
+    if (xyz_problem_stride != 0 && xyz_problem_stride != 3 * static_cast<int64_t>(N))
+        return fail(PNP_E_ARG, "host-pointer calls take xyz_problem_stride 0 or 3*N only");
+    const size_t xyz_n = xyz_problem_stride ? nB * 3 * N : static_cast<size_t>(3) * N;
+    int rc = staging_reserve(st, 2048 + (nB * 6 + xyz_n + 16) * sizeof(double) + nB * 2 * N * sizeof(float));
+    if (rc) return rc;
+    Carver c(st.buf);
+    double *d_rpy = c.take<double>(nB * 3);
+    double *d_t = c.take<double>(nB * 3);
+    double *d_xyz = c.take<double>(xyz_n);
+    float *d_uv = c.take<float>(nB * 2 * N);
+    HIP_TRY(hipMemcpyAsync(d_rpy, rpy_deg, nB * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_t, t, nB * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_xyz, xyz, xyz_n * sizeof(double), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(pnp::project_kernel, dim3(static_cast<unsigned>(nblk)), dim3(kBlock), 0, s, d_rpy, d_t, d_xyz,
+                       xyz_problem_stride, Km, B, N, quantize_q, d_uv);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(uv_out, d_uv, nB * 2 * N * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return PNP_OK;
+}
+
 int pnp_set_lanes_per_problem(int32_t lanes)
 {
     g_err[0] = 0;

@@ -31,6 +31,10 @@ struct KinvRows {  // first two rows of K^-1: nu_x = a00 u + a01 v + a02, nu_y =
     double a00, a01, a02, a10, a11, a12;
 };
 
+struct Mat3 {  // row-major 3x3, passed to kernels by value
+    double m[9];
+};
+
 struct QeifParams {
     double q_inv, r_quat, r_delta, omega0, rel_tol, res_old0;
     int max_it;
@@ -763,6 +767,46 @@ __global__ __launch_bounds__(kBlock) void dlt_kernel(
         store_pose(s.problem, R, t, R_out, t_out);
         if (res_out) res_out[s.problem] = static_cast<float>(res);
         if (rpy_out) store_rpy(s.problem, R, rpy_out);
+    }
+}
+
+// Synthetic-input generator: pose (roll, yaw, pitch in degrees; t) -> pixels of a pattern.
+// R = E_roll E_pitch E_yaw with the yaw sign flipped first; ray = K (R p + t); the ray is
+// divided by |ray_z| and, if q > 0, rounded half-to-even onto a grid of step q.
+// One lane per pose; float64 throughout, pixels stored as float32.
+__global__ __launch_bounds__(kBlock) void project_kernel(
+    const double *__restrict__ rpy_deg, const double *__restrict__ t, const double *__restrict__ xyz,
+    int64_t xyz_stride, Mat3 Kmat, int64_t B, int N, double q, float *__restrict__ uv_out)
+{
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (b >= B) return;
+    constexpr double kD2R = 3.14159265358979323846 / 180.0;
+    const double roll = rpy_deg[3 * b] * kD2R, yaw = -rpy_deg[3 * b + 1] * kD2R, pitch = rpy_deg[3 * b + 2] * kD2R;
+    const double c1 = cos(roll), s1 = sin(roll), c2 = cos(yaw), s2 = sin(yaw), c3 = cos(pitch), s3 = sin(pitch);
+    // E_pitch E_yaw = [[c2, 0, -s2], [s3 s2, c3, s3 c2], [c3 s2, -s3, c3 c2]], then E_roll on the left
+    const double m00 = c2, m01 = 0.0, m02 = -s2;
+    const double m10 = s3 * s2, m11 = c3, m12 = s3 * c2;
+    const double m20 = c3 * s2, m21 = -s3, m22 = c3 * c2;
+    const double R[9] = {c1 * m00 + s1 * m10, c1 * m01 + s1 * m11, c1 * m02 + s1 * m12,
+                         -s1 * m00 + c1 * m10, -s1 * m01 + c1 * m11, -s1 * m02 + c1 * m12,
+                         m20, m21, m22};
+    const double tx = t[3 * b], ty = t[3 * b + 1], tz = t[3 * b + 2];
+    const double *P = xyz + b * xyz_stride;
+    for (int i = 0; i < N; ++i) {
+        const double X = P[3 * i], Y = P[3 * i + 1], Z = P[3 * i + 2];
+        const double cx = R[0] * X + R[1] * Y + R[2] * Z + tx;
+        const double cy = R[3] * X + R[4] * Y + R[5] * Z + ty;
+        const double cz = R[6] * X + R[7] * Y + R[8] * Z + tz;
+        const double rx = Kmat.m[0] * cx + Kmat.m[1] * cy + Kmat.m[2] * cz;
+        const double ry = Kmat.m[3] * cx + Kmat.m[4] * cy + Kmat.m[5] * cz;
+        const double rz = Kmat.m[6] * cx + Kmat.m[7] * cy + Kmat.m[8] * cz;
+        double u = rx / fabs(rz), v = ry / fabs(rz);
+        if (q > 0.0) {
+            u = rint(u / q) * q;
+            v = rint(v / q) * q;
+        }
+        uv_out[(b * N + i) * 2] = static_cast<float>(u);
+        uv_out[(b * N + i) * 2 + 1] = static_cast<float>(v);
     }
 }
 

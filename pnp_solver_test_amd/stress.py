@@ -1,0 +1,110 @@
+"""Batched counterparts of the reference's Monte-Carlo drivers.
+
+random_stress(): scripts/random_stress_test.py:226-486 as ONE projection launch and ONE solver
+launch - pose draws in the driver's order (:245-258), projection + pixel quantisation
+(PNP_SOLVER_LIB.py:4532-4557), solve_pnp on the six-landmark subset, the 10 cm / 10 deg pass
+criteria (:374-377, TEST_TOOLBOX.py:55-62), ground-truth classes (TEST_TOOLBOX.py:133-247) and
+the per-class error statistics (TEST_TOOLBOX.py:892-937, :1173-1188).
+
+landmark_noise_sweep(): scripts/LM_noise_test.py:141-175, :253-360 - yaw x noise-sigma grid of
+noisy landmark sets, all cells solved in one launch, yaw-error mean / stddev / MAE meshes.
+
+The arithmetic of projection and solving runs on the GPU; the statistics are a few NumPy
+reductions over the downloaded results (the reference's report layer).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import batch as _batch
+from . import synth
+
+#: "drpy_expand" ground-truth classes (TEST_TOOLBOX.py:137-162): labels and np.digitize bins
+DRPY_CLASSES = {
+    "depth": ([str(int(v)) for v in np.arange(20.0, 240.1, 20)], list(np.arange(20.0, 240.1, 20)[:-1] + 10.0)),
+    "roll": (["-45", "-25", "0", "25", "45"], [-35, -15, 15, 35]),
+    "pitch": (["-30", "-15", "0", "15", "30"], [-23, -8, 8, 23]),
+    "yaw": (["-40", "-20", "0", "20", "40"], [-30, -10, 10, 30]),
+}
+
+
+def classify(values, class_name):
+    """Class label of every value (TEST_TOOLBOX.classify_drpy, :239-247)."""
+    labels, bins = DRPY_CLASSES[class_name]
+    return np.array(labels)[np.digitize(values, bins)]
+
+
+def error_statistics(est, gt, unit_scale=1.0):
+    """The reference's statistics of an estimate against ground truth
+    (TEST_TOOLBOX.get_statistic_of_result, :892-937)."""
+    est = np.asarray(est, dtype=np.float64)
+    gt = np.asarray(gt, dtype=np.float64)
+    n = est.shape[0]
+    if n == 0:
+        return None
+    err = est - gt
+    mean = np.average(err)
+    return dict(n_data=n, m_ratio=np.average(est / gt), mean=mean * unit_scale,
+                stddev=(np.sum((err - mean) ** 2) / n) ** 0.5 * unit_scale,
+                max_dev=np.max(np.abs(err - mean)) * unit_scale,
+                MAE_2_GT=np.sum(np.abs(err)) / n * unit_scale,
+                MAE_2_mean=np.sum(np.abs(err - mean)) / n * unit_scale)
+
+
+def random_stress(count, seed=42, pattern15=None, lm_rows=None, K=synth.K_DEFAULT, is_quantized=True,
+                  device="cuda:0", error_bound=(10.0, 10.0, 10.0, 10.0)):
+    """Run `count` random-stress samples.  pattern15: (M,3) golden pattern used to generate the
+    landmarks (default: the six solver landmarks only); lm_rows: rows of it the solver uses.
+    Returns a dict with the ground truth, the estimates, `passed` (count,4) = depth, roll, pitch,
+    yaw within bounds, `pass_count`, and `stats` = per distance class (and "all") statistics of
+    depth (cm), roll, pitch and yaw (deg) errors."""
+    if pattern15 is None:
+        pattern15, lm_rows = synth.PATTERN6, list(range(6))
+    pattern15 = np.asarray(pattern15, dtype=np.float64)
+    rng = np.random.default_rng(seed)
+    roll, pitch, yaw, t = synth.sample_stress_poses(rng, count)
+    uv_all = _batch.project_batch(roll, yaw, pitch, t, pattern15, K, 1.0 if is_quantized else 0.0, device=device)
+    uv = uv_all[:, lm_rows, :].contiguous()
+    out = _batch.solve_pnp_batch(uv, pattern15[lm_rows].astype(np.float32), K, method="qeif")
+    res = {k: v.detach().cpu().numpy() for k, v in out.items()}
+    est = np.stack([res["t3"].astype(np.float64) * 100.0, res["rpy_deg"][:, 0], res["rpy_deg"][:, 2],
+                    res["rpy_deg"][:, 1]], axis=1)
+    gt = np.stack([t[:, 2] * 100.0, roll, pitch, yaw], axis=1)
+    passed = np.abs(est - gt) < np.asarray(error_bound)[None, :]
+    classes = {"distance": classify(gt[:, 0], "depth"), "roll": classify(roll, "roll"),
+               "pitch": classify(pitch, "pitch"), "yaw": classify(yaw, "yaw")}
+    stats = {}
+    for label in list(dict.fromkeys(classes["distance"].tolist())) + ["all"]:
+        m = slice(None) if label == "all" else classes["distance"] == label
+        stats[label] = dict(depth=error_statistics(res["t3"][m], t[m, 2], 100.0),
+                            roll=error_statistics(res["rpy_deg"][m, 0], roll[m]),
+                            pitch=error_statistics(res["rpy_deg"][m, 2], pitch[m]),
+                            yaw=error_statistics(res["rpy_deg"][m, 1], yaw[m]))
+    return dict(roll_gt=roll, pitch_gt=pitch, yaw_gt=yaw, t_gt=t, uv=uv_all.detach().cpu().numpy(), classes=classes,
+                passed=passed, pass_count=passed.sum(axis=1), stats=stats, **res)
+
+
+def landmark_noise_sweep(yaw_list, sigma_list, noise, pattern15, lm_rows, K=synth.K_DEFAULT, fixed_depth=1.0,
+                         bbox_resolution=112.0, bbox_size=30.0, device="cuda:0"):
+    """Yaw x noise-sigma sweep.  noise: (n_noise, M, 2) unit-variance draws (the reference uses
+    default_rng(42).multivariate_normal(0, I2, (2000, 15))), scaled by sigma*bbox_size/bbox_resolution
+    and added to the clean landmarks, which are quantised with step bbox_size/bbox_resolution.
+    Returns yaw_est (n_yaw, n_sigma, n_noise) and the three meshes."""
+    import torch
+    yaw_list = np.asarray(yaw_list, dtype=np.float64)
+    sigma_list = np.asarray(sigma_list, dtype=np.float64)
+    pattern15 = np.asarray(pattern15, dtype=np.float64)
+    ny, ns, nn = len(yaw_list), len(sigma_list), noise.shape[0]
+    q = 1.0 / bbox_resolution * bbox_size
+    zeros = np.zeros(ny)
+    t = np.tile(np.array([0.0, 0.0, fixed_depth]), (ny, 1))
+    clean = _batch.project_batch(zeros, yaw_list, zeros, t, pattern15, K, q, device=None).astype(np.float64)
+    # float64 on the host exactly as the driver adds it, then ONE rounding to float32
+    scale = (sigma_list / bbox_resolution * bbox_size)[None, :, None, None, None]
+    pts = clean[:, None, None, :, :] + scale * np.asarray(noise, dtype=np.float64)[None, None, :, :, :]
+    uv = np.ascontiguousarray(pts[:, :, :, lm_rows, :].reshape(ny * ns * nn, len(lm_rows), 2), dtype=np.float32)
+    out = _batch.solve_pnp_batch(torch.from_numpy(uv).to(device), pattern15[lm_rows].astype(np.float32), K)
+    yaw_est = out["rpy_deg"][:, 1].detach().cpu().numpy().astype(np.float64).reshape(ny, ns, nn)
+    err = yaw_est - yaw_list[:, None, None]
+    return dict(yaw_est=yaw_est, uv_clean=clean, mesh_mean=err.mean(axis=2), mesh_std=err.std(axis=2),
+                mesh_mae=np.abs(err).mean(axis=2))

@@ -170,3 +170,34 @@ def test_shard_bounds_partition():
     assert pnp.shard_bounds(8 << 20, 3, 8) == (3 << 20, 4 << 20)
     with pytest.raises(ValueError):
         pnp.shard_bounds(10, 4, 4)
+
+
+def test_stress_classes_and_statistics_match_reference_toolbox(golden):
+    """Classification bins and error statistics of the batched driver against what the
+    reference's TEST_TOOLBOX computed for the same 10,000 results."""
+    import json
+    from pnp_solver_test_amd import stress, synth
+    g = golden("stress_qeif_n6")
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "stress_stats.json")))
+    dist = stress.classify(g["t_gt"][:, 2] * 100.0, "depth")
+    assert dist.tolist() == ref["classes"]["distance"]
+    assert stress.classify(g["roll_gt"], "roll").tolist() == ref["classes"]["roll"]
+    assert stress.classify(g["pitch_gt"], "pitch").tolist() == ref["classes"]["pitch"]
+    assert stress.classify(g["yaw_gt"], "yaw").tolist() == ref["classes"]["yaw"]
+    for label, per in ref["stats"].items():
+        m = slice(None) if label == "all" else dist == label
+        mine = dict(depth=stress.error_statistics(g["t3"][m], g["t_gt"][m, 2], 100.0),
+                    roll=stress.error_statistics(g["roll"][m], g["roll_gt"][m]),
+                    pitch=stress.error_statistics(g["pitch"][m], g["pitch_gt"][m]),
+                    yaw=stress.error_statistics(g["yaw"][m], g["yaw_gt"][m]))
+        for q, d in per.items():
+            unit = "cm" if q == "depth" else "deg."
+            assert mine[q]["n_data"] == d["n_data"]
+            assert mine[q]["m_ratio"] == pytest.approx(d["m_ratio"], rel=1e-12)
+            for k in ("mean", "stddev", "max_dev", "MAE_2_GT", "MAE_2_mean"):
+                assert mine[q][k] == pytest.approx(d["%s(%s)" % (k, unit)], rel=1e-9, abs=1e-12)
+    # the vectorised sampler consumes the generator exactly as the per-sample loop does
+    roll, pitch, yaw, t = synth.sample_stress_poses(np.random.default_rng(42), 10000)
+    assert np.array_equal(roll, g["roll_gt"]) and np.array_equal(t, g["t_gt"])
+    uv, _ = synth.stress_batch(10000, 42, pattern=po.pattern_array(po.PATTERN_ALEXANDER))
+    assert np.array_equal(uv, g["uv15"])
