@@ -117,8 +117,10 @@ def main():
         raise SystemExit("bench.py needs a HIP device; the solver has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    distributed = "RANK" in os.environ          # launched by torch.distributed.run, any world size
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=dev)
 
     K = synth.K_DEFAULT
@@ -134,7 +136,7 @@ def main():
         return pnp.solve_pnp_batch(uv, xyz, K, method="qeif", want_rpy=False)
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -150,7 +152,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    if world > 1:
+    if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -251,7 +253,7 @@ def main():
             line["cpu_baseline_c"] = cpu_baseline_c(uv_h, xyz_h, K)
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -90,6 +90,18 @@ int pnp_dlt_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_str
                       float *t_out, float *res_out, float *rpy_out, int32_t ptr_kind,
                       void *hip_stream);
 
+/* Replaces solve_pnp_LM_single_pattern (PNP_SOLVER_LIB.py:2567-2769), the 12-state
+ * Levenberg-Marquardt solver, with its model EKF2_get_hx_H (:3718-3836, options
+ * is_hc0_4_6_linear=False, is_hc1_linear=True) and reconstruction EKF2_reconstruct_R_t_m1
+ * (:3500-3540): num_it iterations (reference: 14, no early exit) of
+ * dx = (J^T J + lambda I)^-1 J^T (z - h) with lambda = 1e-5 in the reference.  res_out is the
+ * reprojection part of the residual at the last linearisation point (:2681).  N is limited by
+ * LDS (64 problems per workgroup): 8N + 12N bytes per problem must fit 48 KB. */
+int pnp_lm12_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_stride,
+                       const double K[9], int64_t B, int32_t N, double lambda, int32_t num_it,
+                       float *R_out, float *t_out, float *res_out, float *rpy_out,
+                       int32_t ptr_kind, void *hip_stream);
+
 /* Replaces get_Euler_from_rotation_matrix(R, is_degree=True) (PNP_SOLVER_LIB.py:4474-4517)
  * for B matrices: R (B,9) -> rpy (B,3) = roll, yaw, pitch in degrees. */
 int pnp_euler_deg_f32(const float *R, int64_t B, float *rpy, int32_t ptr_kind, void *hip_stream);

@@ -8,7 +8,8 @@ the drivers use; the solvers themselves run in the HIP kernels of libpnp_hip.so 
 ctypes.  There is no CPU solver here: without the shared library the import fails.
 
 What runs where
-  * solve_pnp, solve_pnp_QEIF_single_pattern, solve_pnp_single_pattern, and the batched
+  * solve_pnp, solve_pnp_QEIF_single_pattern, solve_pnp_single_pattern,
+    solve_pnp_LM_single_pattern, and the batched
     additions solve_pnp_batch / euler_deg_batch: device kernels.
   * get_rotation_matrix_from_Euler, get_Euler_from_rotation_matrix, perspective_projection*,
     transform_3D_point, unit_vec: host-side NumPy utilities of the synthetic-data generator
@@ -172,7 +173,16 @@ class PNP_SOLVER(object):
         out = _batch.solve_pnp_batch(uv, xyz, self.np_K_camera_est, method="dlt", num_it=3)
         return self._finish(out)
 
-    def solve_pnp_batch(self, uv, xyz=None, *, method="qeif", params=None, num_it=3, want_rpy=True,
+    def solve_pnp_LM_single_pattern(self, np_point_image_dict, np_point_3d_pretransfer_dict, LM_key_list=None):
+        """Reference :2567-2769: the 12-state Levenberg-Marquardt solver.  As there, LM_key_list is
+        ignored: the pattern contributes all its keys in its own order (:2576) and the image dict
+        all of its keys in its own order (:2597)."""
+        uv = self._image_array(np_point_image_dict, list(np_point_image_dict.keys()))
+        xyz = self._pattern_array(np_point_3d_pretransfer_dict, list(np_point_3d_pretransfer_dict.keys()))
+        out = _batch.solve_pnp_batch(uv, xyz, self.np_K_camera_est, method="lm12", num_it=14)
+        return self._finish(out)
+
+    def solve_pnp_batch(self, uv, xyz=None, *, method="qeif", params=None, num_it=None, want_rpy=True,
                         all_patterns=False):
         """Batched addition (no reference counterpart): uv (B,N,2); xyz (N,3) or (B,N,3), or
         None for the six-landmark subset of the currently selected golden pattern (N must then

@@ -29,7 +29,7 @@ PTR_DEVICE = 1
 #: every symbol include/pnp_hip.h declares
 EXPORTS = (
     "pnp_qeif_default_params", "pnp_device_count", "pnp_init", "pnp_qeif_batch_f32",
-    "pnp_dlt_batch_f32", "pnp_euler_deg_f32", "pnp_qeif_multi_batch_f32", "pnp_project_batch_f64",
+    "pnp_dlt_batch_f32", "pnp_euler_deg_f32", "pnp_qeif_multi_batch_f32", "pnp_project_batch_f64", "pnp_lm12_batch_f32",
     "pnp_set_lanes_per_problem", "pnp_get_lanes_per_problem", "pnp_max_points",
     "pnp_last_error", "pnp_version",
 )
@@ -76,6 +76,8 @@ def load():
     lib.pnp_qeif_batch_f32.restype = ctypes.c_int
     lib.pnp_dlt_batch_f32.argtypes = [vp, vp, i64, dp, i64, i32, i32, vp, vp, vp, vp, i32, vp]
     lib.pnp_dlt_batch_f32.restype = ctypes.c_int
+    lib.pnp_lm12_batch_f32.argtypes = [vp, vp, i64, dp, i64, i32, ctypes.c_double, i32, vp, vp, vp, vp, i32, vp]
+    lib.pnp_lm12_batch_f32.restype = ctypes.c_int
     lib.pnp_euler_deg_f32.argtypes = [vp, i64, vp, i32, vp]
     lib.pnp_euler_deg_f32.restype = ctypes.c_int
     lib.pnp_qeif_multi_batch_f32.argtypes = [vp, vp, i32, dp, i64, i32, pp, vp, vp, vp, vp, vp, vp, i32, vp]

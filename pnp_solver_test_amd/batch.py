@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 
-METHODS = ("qeif", "dlt")
+METHODS = ("qeif", "dlt", "lm12")
 
 
 def _is_torch(x) -> bool:
@@ -44,8 +44,8 @@ def _shapes(uv_shape, xyz_shape):
                      % (B, N, tuple(xyz_shape)))
 
 
-def solve_pnp_batch(uv, xyz, K, *, method="qeif", params=None, num_it=3, want_rpy=True,
-                    patterns=None):
+def solve_pnp_batch(uv, xyz, K, *, method="qeif", params=None, num_it=None, want_rpy=True,
+                    patterns=None, lm_lambda=1e-5):
     """Solve B independent PnP problems.
 
     uv       (B, N, 2) float32 pixel coordinates
@@ -54,8 +54,11 @@ def solve_pnp_batch(uv, xyz, K, *, method="qeif", params=None, num_it=3, want_rp
     method   "qeif": quaternion information filter, the reference's live solver
              (solve_pnp_QEIF_single_pattern, :2771-3025);
              "dlt": iterated linear DLT (solve_pnp_single_pattern, :205-430)
+             "lm12": the 12-state Levenberg-Marquardt solver (solve_pnp_LM_single_pattern,
+             :2567-2769); it diverges on a sizeable share of off-axis poses, as the original does
     params   QEIF tunables from make_params(); None = reference defaults
-    num_it   DLT rounds (reference: 3)
+    num_it   DLT rounds (reference: 3) / LM iterations (reference: 14; pass num_it=14)
+    lm_lambda LM damping (reference: 1e-5)
     patterns optional (P, N, 3): QEIF against P shared patterns, keeping per problem the first
              with the smallest residual (the pattern loop of solve_pnp, :166-199); `xyz` is
              then ignored and the result gains "pattern_id"
@@ -68,11 +71,14 @@ def solve_pnp_batch(uv, xyz, K, *, method="qeif", params=None, num_it=3, want_rp
         raise ValueError("method must be one of %s" % (METHODS,))
     if patterns is not None and method != "qeif":
         raise ValueError("multiple patterns are supported by method='qeif' only")
+    if num_it is None:
+        num_it = 14 if method == "lm12" else 3
     lib = _lib.load()
     Kc = _lib.k_array(K)
+    extra = (num_it, float(lm_lambda))
     if _is_torch(uv):
-        return _solve_torch(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns)
-    return _solve_numpy(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns)
+        return _solve_torch(lib, uv, xyz, Kc, method, params, extra, want_rpy, patterns)
+    return _solve_numpy(lib, uv, xyz, Kc, method, params, extra, want_rpy, patterns)
 
 
 def _solve_numpy(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns):
@@ -157,8 +163,11 @@ def _solve_torch(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns):
 def _call(lib, method, uv, xyz, stride, n_pat, Kc, B, N, params, num_it, R, t, res, iters, rpy, pid,
           kind, stream, multi):
     pref = ctypes.byref(params) if params is not None else None
+    num_it, lm_lambda = num_it
     if method == "dlt":
         rc = lib.pnp_dlt_batch_f32(uv, xyz, stride, Kc, B, N, int(num_it), R, t, res, rpy, kind, stream)
+    elif method == "lm12":
+        rc = lib.pnp_lm12_batch_f32(uv, xyz, stride, Kc, B, N, lm_lambda, int(num_it), R, t, res, rpy, kind, stream)
     elif multi:
         rc = lib.pnp_qeif_multi_batch_f32(uv, xyz, n_pat, Kc, B, N, pref, R, t, res, iters, rpy, pid,
                                           kind, stream)

@@ -403,6 +403,49 @@ int pnp_dlt_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_str
     });
 }
 
+static int launch_lm12(hipStream_t s, const float *uv, const float *xyz, int64_t xyz_stride,
+                       const pnp::KinvRows &ki, int64_t B, int N, double lambda, int num_it, float *R,
+                       float *t, float *res, float *rpy)
+{
+    if (B == 0) return PNP_OK;
+    const size_t pb = pnp::kLmBlock;
+    const size_t lds = (pb * 2 * N + (xyz_stride ? pb * 3 * N : static_cast<size_t>(3) * N)) * sizeof(float);
+    if (lds > static_cast<size_t>(kLdsBudget))
+        return fail(PNP_E_ARG, "N = %d needs %zu bytes of LDS per workgroup in the LM solver (max %d)", N, lds,
+                    kLdsBudget);
+    const int64_t nblk = (B + pnp::kLmBlock - 1) / pnp::kLmBlock;
+    if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
+    hipLaunchKernelGGL(pnp::lm12_kernel, dim3(static_cast<unsigned>(nblk)), dim3(pnp::kLmBlock), lds, s, uv, xyz,
+                       xyz_stride, ki, B, N, lambda, num_it, R, t, res, rpy);
+    HIP_TRY(hipGetLastError());
+    return PNP_OK;
+}
+
+int pnp_lm12_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_stride, const double K[9],
+                       int64_t B, int32_t N, double lambda, int32_t num_it, float *R_out, float *t_out,
+                       float *res_out, float *rpy_out, int32_t ptr_kind, void *hip_stream)
+{
+    g_err[0] = 0;
+    int rc = check_common(uv, xyz, xyz_problem_stride, K, B, N, R_out, t_out, ptr_kind);
+    if (rc) return rc;
+    if (num_it < 1) return fail(PNP_E_ARG, "num_it = %d must be >= 1", num_it);
+    if (!(lambda >= 0.0)) return fail(PNP_E_ARG, "lambda must be >= 0");
+    pnp::KinvRows ki;
+    rc = kinv_rows(K, ki);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (B == 0) return PNP_OK;
+    if (ptr_kind == PNP_PTR_DEVICE)
+        return launch_lm12(s, uv, xyz, xyz_problem_stride, ki, B, N, lambda, num_it, R_out, t_out, res_out, rpy_out);
+    if (xyz_problem_stride != 0 && xyz_problem_stride != 3 * static_cast<int64_t>(N))
+        return fail(PNP_E_ARG, "host-pointer calls take xyz_problem_stride 0 or 3*N only");
+    const size_t xyz_floats = xyz_problem_stride ? static_cast<size_t>(B) * 3 * N : static_cast<size_t>(3) * N;
+    SolveIO h{uv, xyz, R_out, t_out, res_out, rpy_out, nullptr, nullptr};
+    return with_host_staging(s, B, N, xyz_floats, h, [&](const SolveIO &d) {
+        return launch_lm12(s, d.uv, d.xyz, xyz_problem_stride, ki, B, N, lambda, num_it, d.R, d.t, d.res, d.rpy);
+    });
+}
+
 int pnp_euler_deg_f32(const float *R, int64_t B, float *rpy, int32_t ptr_kind, void *hip_stream)
 {
     g_err[0] = 0;
