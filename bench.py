@@ -95,8 +95,8 @@ def cpu_baseline_c(uv, xyz, K):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=BATCH, help="problems per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
@@ -218,7 +218,7 @@ def main():
         }
         if world == 1 and not args.no_other_configs:
             other = {}
-            n_small = max(5, args.steps // 2)
+            n_small = max(5, min(50, args.steps // 2))
             P6 = torch.from_numpy(synth.PATTERN6.astype(np.float32)).to(dev)
             ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, P6, K, want_rpy=False), n_small, 3)
             other["qeif_n6_shared_pattern"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4),
@@ -233,6 +233,10 @@ def main():
             other["configs[1]_dlt_n6_b1m"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4),
                                                   achieved_GBps=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4),
                                                   valu_fp64_TFLOPs=round(B * dlt_flops(6) / (ms * 1e-3) / 1e12, 2))
+            B_lm = 1 << 18
+            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv[:B_lm], xyz[:B_lm], K, method="lm12", want_rpy=False),
+                               5, 1)
+            other["lm12_n6_b256k (secondary solver)"] = dict(solves_per_s=round(B_lm / ms * 1e3, 1), kernel_ms=round(ms, 4))
             B68 = 1 << 18
             P68 = synth.face68()
             uv68_h, _ = synth.stress_batch(B68, seed=46, pattern=P68, K=K, is_quantized=True, chunk=1 << 15)

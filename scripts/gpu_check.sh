@@ -20,11 +20,11 @@ step 240 smoke.log python -u -c "import __graft_entry__ as g; g.smoke()" || { ta
 tail -2 gpurun_out/smoke.log
 step 600 pytest_gpu.log python -u -m pytest tests -m gpu -q --timeout 180 --timeout-method thread -p no:cacheprovider
 tail -25 gpurun_out/pytest_gpu.log
-step 300 bench.log python -u bench.py --steps 20 --warmup 3 || { tail -30 gpurun_out/bench.log; exit 1; }
+step 300 bench.log python -u bench.py || { tail -30 gpurun_out/bench.log; exit 1; }
 tail -3 gpurun_out/bench.log
 if [ "${PROFILE:-1}" = "1" ]; then
     cd /tmp
-    step 300 rocprof_stats.log rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o bench -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline
+    step 300 rocprof_stats.log rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o bench -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 50 --warmup 5 --no-cpu-baseline
     cd "$GRAFT_REPO_ROOT"
     ls -R gpurun_out/prof | head -20
 fi
