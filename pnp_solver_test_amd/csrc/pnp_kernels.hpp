@@ -44,16 +44,14 @@ struct QeifParams {
 // scalar helpers
 // ------------------------------------------------------------------------------------------
 
-// 1/d to full double precision: hardware seed plus two Newton steps (the seed of
-// v_rcp_f64 is not correctly rounded).  d == 0 or non-finite input propagates NaN/inf.
+// 1/d to full double precision.  The hardware seed r0 of v_rcp_f64 carries a relative error
+// e = 1 - d r0 of about 5e-8; 1/d = r0 (1 + e + e^2 + ...), and r0 (1 + e + e^2) leaves e^3 ~
+// 1e-22, below rounding.  d == 0 or non-finite input propagates NaN/inf.
 __device__ __forceinline__ double rcp(double d)
 {
-    double r = __builtin_amdgcn_rcp(d);
-    double e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(e, r, r);
-    e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(e, r, r);
-    return r;
+    const double r0 = __builtin_amdgcn_rcp(d);
+    const double e = __builtin_fma(-d, r0, 1.0);
+    return __builtin_fma(__builtin_fma(e, e, e), r0, r0);
 }
 
 // sqrt(x) for 0 <= x in the normal range: hardware reciprocal-square-root seed, one coupled
@@ -343,103 +341,137 @@ __device__ __forceinline__ void gamma_matrix(const double (&x)[6], double (&phi)
 // The reference forms zeta = Obar x + q_inv H^T (z - h + H x) and x = Sigma zeta; since
 // Omega = Obar + q_inv H^T H these are the same vector, x + Sigma q_inv H^T (z - h).
 // Its stopping rule |(res - res_old)/res_old| < rel_tol is the same inequality (res_old > 0).
+struct QeifState {
+    double x[6];     // [q(4), delta1, delta2]
+    double T[21];    // packed lower 6x6; holds -Sigma between iterations (see qeif_iterate)
+    double res_old;  // residual norm of the previous iteration
+    double res;      // residual norm at the last linearisation point
+    int k;           // iterations done
+};
+
+__device__ __forceinline__ void qeif_init(QeifState &st, const QeifParams &p)
+{
+    st.x[0] = 1.0;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) st.x[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 21; ++i) st.T[i] = 0.0;
+    const double s0 = -1.0 / p.omega0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) st.T[tri(i, i)] = s0;
+    st.res_old = p.res_old0;
+    st.res = 1.0e5;
+    st.k = 0;
+}
+
+// Scalars derived from the parameters once per kernel.
+struct QeifConsts {
+    double c, c_inv, dd;  // sqrt(q_inv), its reciprocal, q_inv * N
+    __device__ __forceinline__ QeifConsts(const QeifParams &p, int N)
+        : c(sqrt(p.q_inv)), c_inv(1.0 / sqrt(p.q_inv)), dd(p.q_inv * static_cast<double>(N)) {}
+};
+
+// One iteration; returns true when the stopping rule fires.  T is swept twice and changes
+// sign each time: -Sigma on entry, Obar after the first sweep, -Sigma again on exit.
+template <int LPI, int NCT, typename PointFetch>
+__device__ __forceinline__ bool qeif_iterate(QeifState &st, const PointFetch &pts, int N, int lane_in_group,
+                                             const QeifParams &p, const QeifConsts &kc)
+{
+    double(&x)[6] = st.x;
+    double(&T)[21] = st.T;
+    const double c = kc.c;
+    ++st.k;
+    // predict: -(Sigma + R_p), then sweep -> (Sigma + R_p)^-1 = Obar
+#pragma unroll
+    for (int i = 0; i < 4; ++i) T[tri(i, i)] -= p.r_quat;
+    T[tri(4, 4)] -= p.r_delta;
+    T[tri(5, 5)] -= p.r_delta;
+    sweep_neg_inverse<6>(T);
+    // update: Omega = Obar + q_inv H^T H, accumulated point by point
+    const double qs[4] = {2.0 * c * x[0], 2.0 * c * x[1], 2.0 * c * x[2], 2.0 * c * x[3]};
+    const double hq[4] = {0.5 * x[0], 0.5 * x[1], 0.5 * x[2], 0.5 * x[3]};
+    double g[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double ss = 0.0;
+    if constexpr (LPI == 1) {
+        if constexpr (NCT > 0) {  // the lane owns all NCT points, held in registers
+#pragma unroll
+            for (int i = 0; i < NCT; ++i) {
+                double X, Y, Z, bx, by;
+                pts(i, X, Y, Z, bx, by);
+                qeif_point(T, g, ss, qs, hq, c, x[4], x[5], X, Y, Z, bx, by);
+            }
+        } else {
+            for (int i = 0; i < N; ++i) {
+                double X, Y, Z, bx, by;
+                pts(i, X, Y, Z, bx, by);
+                qeif_point(T, g, ss, qs, hq, c, x[4], x[5], X, Y, Z, bx, by);
+            }
+        }
+    } else {
+        double M[21];  // this lane's share; only the (q,q), (d1,q), (d2,q) entries are used
+#pragma unroll
+        for (int i = 0; i < 21; ++i) M[i] = 0.0;
+        for (int i = lane_in_group; i < N; i += LPI) {
+            double X, Y, Z, bx, by;
+            pts(i, X, Y, Z, bx, by);
+            qeif_point(M, g, ss, qs, hq, c, x[4], x[5], X, Y, Z, bx, by);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) T[tri(i, j)] += group_sum<LPI>(M[tri(i, j)]);
+            T[tri(4, i)] += group_sum<LPI>(M[tri(4, i)]);
+            T[tri(5, i)] += group_sum<LPI>(M[tri(5, i)]);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) g[i] = group_sum<LPI>(g[i]);
+        ss = group_sum<LPI>(ss);
+    }
+    T[tri(4, 4)] += kc.dd;
+    T[tri(5, 5)] += kc.dd;
+    g[4] *= c;
+    g[5] *= c;
+    st.res = sqrt_pos(ss) * kc.c_inv;
+    sweep_neg_inverse<6>(T);  // T = -Sigma
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double dx = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) dx = __builtin_fma(T[i >= j ? tri(i, j) : tri(j, i)], g[j], dx);
+        x[i] -= dx;
+    }
+    const bool stop = fabs(st.res - st.res_old) < p.rel_tol * st.res_old;
+    st.res_old = st.res;
+    return stop;
+}
+
+// reconstruct: R = Gamma(q)/gamma, t3 = 1/gamma, t = [d1, d2, 1] t3
+__device__ __forceinline__ void qeif_finish(const QeifState &st, double (&R)[9], double (&t)[3])
+{
+    double phi[9], gamma;
+    gamma_matrix(st.x, phi, gamma);
+    const double t3 = 1.0 / gamma;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = phi[i] * t3;
+    t[0] = st.x[4] * t3;
+    t[1] = st.x[5] * t3;
+    t[2] = t3;
+}
+
 template <int LPI, int NCT, typename PointFetch>
 __device__ __forceinline__ void qeif_solve(const PointFetch &pts, int N, int lane_in_group,
                                            const QeifParams &p, double (&R)[9], double (&t)[3],
                                            double &res_out, int &iters_out)
 {
-    double x[6] = {1.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    // T is swept twice per iteration and changes sign each time: it holds -Sigma at the top of
-    // the loop, Obar after the first sweep and -Sigma again after the second.
-    double T[21];
-#pragma unroll
-    for (int i = 0; i < 21; ++i) T[i] = 0.0;
-    {
-        const double s0 = -1.0 / p.omega0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) T[tri(i, i)] = s0;
+    QeifState st;
+    qeif_init(st, p);
+    const QeifConsts kc(p, N);
+    while (st.k < p.max_it) {
+        if (qeif_iterate<LPI, NCT>(st, pts, N, lane_in_group, p, kc)) break;
     }
-    const double c = sqrt(p.q_inv);
-    const double c_inv = 1.0 / c;
-    const double dd = p.q_inv * static_cast<double>(N);
-    double res_old = p.res_old0, res = 1.0e5;
-    int k = 0;
-    while (k < p.max_it) {
-        ++k;
-        // predict: -(Sigma + R_p), then sweep -> (Sigma + R_p)^-1 = Obar
-#pragma unroll
-        for (int i = 0; i < 4; ++i) T[tri(i, i)] -= p.r_quat;
-        T[tri(4, 4)] -= p.r_delta;
-        T[tri(5, 5)] -= p.r_delta;
-        sweep_neg_inverse<6>(T);
-        // update: Omega = Obar + q_inv H^T H, accumulated point by point
-        const double qs[4] = {2.0 * c * x[0], 2.0 * c * x[1], 2.0 * c * x[2], 2.0 * c * x[3]};
-        const double hq[4] = {0.5 * x[0], 0.5 * x[1], 0.5 * x[2], 0.5 * x[3]};
-        double g[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        double ss = 0.0;
-        if constexpr (LPI == 1) {
-            if constexpr (NCT > 0) {  // the lane owns all NCT points, held in registers
-#pragma unroll
-                for (int i = 0; i < NCT; ++i) {
-                    double X, Y, Z, bx, by;
-                    pts(i, X, Y, Z, bx, by);
-                    qeif_point(T, g, ss, qs, hq, c, x[4], x[5], X, Y, Z, bx, by);
-                }
-            } else {
-                for (int i = 0; i < N; ++i) {
-                    double X, Y, Z, bx, by;
-                    pts(i, X, Y, Z, bx, by);
-                    qeif_point(T, g, ss, qs, hq, c, x[4], x[5], X, Y, Z, bx, by);
-                }
-            }
-        } else {
-            double M[21];  // this lane's share; only the (q,q), (d1,q), (d2,q) entries are used
-#pragma unroll
-            for (int i = 0; i < 21; ++i) M[i] = 0.0;
-            for (int i = lane_in_group; i < N; i += LPI) {
-                double X, Y, Z, bx, by;
-                pts(i, X, Y, Z, bx, by);
-                qeif_point(M, g, ss, qs, hq, c, x[4], x[5], X, Y, Z, bx, by);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int j = 0; j <= i; ++j) T[tri(i, j)] += group_sum<LPI>(M[tri(i, j)]);
-                T[tri(4, i)] += group_sum<LPI>(M[tri(4, i)]);
-                T[tri(5, i)] += group_sum<LPI>(M[tri(5, i)]);
-            }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) g[i] = group_sum<LPI>(g[i]);
-            ss = group_sum<LPI>(ss);
-        }
-        T[tri(4, 4)] += dd;
-        T[tri(5, 5)] += dd;
-        g[4] *= c;
-        g[5] *= c;
-        res = sqrt(ss) * c_inv;
-        sweep_neg_inverse<6>(T);  // T = -Sigma
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            double dx = 0.0;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) dx = __builtin_fma(T[i >= j ? tri(i, j) : tri(j, i)], g[j], dx);
-            x[i] -= dx;
-        }
-        const bool stop = fabs(res - res_old) < p.rel_tol * res_old;
-        res_old = res;
-        if (stop) break;
-    }
-    // reconstruct: R = Gamma(q)/gamma, t3 = 1/gamma, t = [d1, d2, 1] t3
-    double phi[9], gamma;
-    gamma_matrix(x, phi, gamma);
-    const double t3 = 1.0 / gamma;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) R[i] = phi[i] * t3;
-    t[0] = x[4] * t3;
-    t[1] = x[5] * t3;
-    t[2] = t3;
-    res_out = res;
-    iters_out = k;
+    qeif_finish(st, R, t);
+    res_out = st.res;
+    iters_out = st.k;
 }
 
 // ------------------------------------------------------------------------------------------
