@@ -251,6 +251,16 @@ def main():
                 bytes_per_solve=8 * 68 + 48, achieved_GBps=round(gbs, 1),
                 lanes_per_problem=pnp._lib.load().pnp_get_lanes_per_problem(B68, 68, 0),
                 valu_fp64_TFLOPs=round(B68 * qeif_flops(68, it68) / (ms * 1e-3) / 1e12, 2))
+            uv64, xyz64 = uv.double(), xyz.double()          # the reference's own dtype end to end
+            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv64, xyz64, K, want_rpy=False), n_small, 3)
+            other["qeif_n6_b1m_float64_io"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4),
+                                                   bytes_per_solve=2 * bytes_per_solve)
+            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv64, xyz64, K, method="dlt", want_rpy=False),
+                               n_small, 3)
+            gbs = B * (2 * bytes_per_solve) / (ms * 1e-3) / 1e9
+            other["dlt_n6_b1m_float64_io"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4),
+                                                  achieved_GBps=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4))
+            del uv64, xyz64
             line["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:   # last: the GPU idles (and clocks down) meanwhile
             line["cpu_baseline"] = cpu_baseline(uv_h, xyz_h, K)

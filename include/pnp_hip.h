@@ -13,7 +13,10 @@
  *   - K is the 3x3 camera matrix in float64, row-major (np_K_camera_est of the reference
  *     constructor, PNP_SOLVER_LIB.py:10-14).  It is inverted in float64 on the host, as the
  *     reference does with numpy.linalg.inv (:2811, :3097).
- *   - Arithmetic is float64 on float32 inputs; outputs are rounded to float32 once.
+ *   - Arithmetic is always float64.  The _f32 entry points read float32 arrays and round
+ *     their outputs to float32 once; the _f64 entry points take and return float64 arrays
+ *     (the reference's own dtype) and otherwise behave identically: same kernels, same
+ *     arguments, twice the bytes per problem.
  *   - ptr_kind: PNP_PTR_HOST = every array pointer is host memory (the library stages
  *     through device buffers and synchronises before returning); PNP_PTR_DEVICE = every
  *     array pointer is device memory on the current HIP device (the call only enqueues work
@@ -96,7 +99,7 @@ int pnp_dlt_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_str
  * (:3500-3540): num_it iterations (reference: 14, no early exit) of
  * dx = (J^T J + lambda I)^-1 J^T (z - h) with lambda = 1e-5 in the reference.  res_out is the
  * reprojection part of the residual at the last linearisation point (:2681).  N is limited by
- * LDS (64 problems per workgroup): 8N + 12N bytes per problem must fit 48 KB. */
+ * LDS (64 problems per workgroup): (2N + 3N) elements per problem must fit 48 KB. */
 int pnp_lm12_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_stride,
                        const double K[9], int64_t B, int32_t N, double lambda, int32_t num_it,
                        float *R_out, float *t_out, float *res_out, float *rpy_out,
@@ -116,6 +119,28 @@ int pnp_qeif_multi_batch_f32(const float *uv, const float *xyz, int32_t n_patter
                              float *rpy_out, int32_t *pattern_id_out, int32_t ptr_kind,
                              void *hip_stream);
 
+/* float64 flavours of the five entry points above: every float* becomes double* (strides are
+ * counted in doubles), everything else is unchanged.  They reproduce the reference to the
+ * round-off of float64 rather than to that of float32 inputs. */
+int pnp_qeif_batch_f64(const double *uv, const double *xyz, int64_t xyz_problem_stride,
+                       const double K[9], int64_t B, int32_t N, const pnp_qeif_params *p,
+                       double *R_out, double *t_out, double *res_out, int32_t *iters_out,
+                       double *rpy_out, int32_t ptr_kind, void *hip_stream);
+int pnp_dlt_batch_f64(const double *uv, const double *xyz, int64_t xyz_problem_stride,
+                      const double K[9], int64_t B, int32_t N, int32_t num_it, double *R_out,
+                      double *t_out, double *res_out, double *rpy_out, int32_t ptr_kind,
+                      void *hip_stream);
+int pnp_lm12_batch_f64(const double *uv, const double *xyz, int64_t xyz_problem_stride,
+                       const double K[9], int64_t B, int32_t N, double lambda, int32_t num_it,
+                       double *R_out, double *t_out, double *res_out, double *rpy_out,
+                       int32_t ptr_kind, void *hip_stream);
+int pnp_euler_deg_f64(const double *R, int64_t B, double *rpy, int32_t ptr_kind, void *hip_stream);
+int pnp_qeif_multi_batch_f64(const double *uv, const double *xyz, int32_t n_patterns,
+                             const double K[9], int64_t B, int32_t N, const pnp_qeif_params *p,
+                             double *R_out, double *t_out, double *res_out, int32_t *iters_out,
+                             double *rpy_out, int32_t *pattern_id_out, int32_t ptr_kind,
+                             void *hip_stream);
+
 /* Synthetic-input generator of the reference's drivers for B poses: replaces
  * get_rotation_matrix_from_Euler(roll, yaw, pitch, is_degree=True) (PNP_SOLVER_LIB.py:4442-4472)
  * followed by perspective_projection / perspective_projection_golden_landmarks
@@ -123,17 +148,19 @@ int pnp_qeif_multi_batch_f32(const float *uv, const float *xyz, int32_t n_patter
  *   rpy_deg (B,3) roll, yaw, pitch in degrees;  t (B,3);  xyz (N,3) shared (stride 0) or
  *   (B,N,3) with xyz_problem_stride doubles between problems;  K (3,3) host pointer.
  *   quantize_q > 0 rounds the pixels half-to-even onto a grid of that step (is_quantized=True),
- *   quantize_q = 0 leaves them unquantised.   uv_out (B,N,2) float32. */
+ *   quantize_q = 0 leaves them unquantised.   uv_out (B,N,2): float32 if uv_is_f64 == 0,
+ *   float64 otherwise, ready for the solver entry points of the same flavour. */
 int pnp_project_batch_f64(const double *rpy_deg, const double *t, const double *xyz,
                           int64_t xyz_problem_stride, const double K[9], int64_t B, int32_t N,
-                          double quantize_q, float *uv_out, int32_t ptr_kind, void *hip_stream);
+                          double quantize_q, void *uv_out, int32_t uv_is_f64, int32_t ptr_kind,
+                          void *hip_stream);
 
 /* How many lanes of a wavefront cooperate on one problem: 1, 2, 4, 8, 16, 32 or 64
  * (64 = one wavefront per problem); 0 restores the automatic choice from (B, N).
  * Process-wide; meant for tuning and tests.  No reference counterpart. */
 int pnp_set_lanes_per_problem(int32_t lanes);
 
-/* The value the next launch would use for (B, N). */
+/* The value the next float32 launch would use for (B, N). */
 int pnp_get_lanes_per_problem(int64_t B, int32_t N, int64_t xyz_problem_stride);
 
 /* Largest N accepted by the solvers. */

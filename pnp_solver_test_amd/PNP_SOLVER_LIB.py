@@ -14,8 +14,9 @@ What runs where
   * get_rotation_matrix_from_Euler, get_Euler_from_rotation_matrix, perspective_projection*,
     transform_3D_point, unit_vec: host-side NumPy utilities of the synthetic-data generator
     (one 3x3 matrix or one point per call), float64 like the reference.
-Inputs of the device solvers are rounded to float32 (pixels and pattern coordinates);
-results come back as float32 values widened to the float64 types the reference returns.
+The dict-based calls (one problem each) hand float64 arrays to the float64 flavour of the
+kernels and so agree with the reference to float64 round-off; solve_pnp_batch follows the
+dtype of the array it is given (float32 halves the memory traffic of large batches).
 """
 from __future__ import annotations
 
@@ -109,9 +110,9 @@ class PNP_SOLVER(object):
     # ---- dict <-> array glue --------------------------------------------------------------
     @staticmethod
     def _image_array(np_point_image_dict, keys):
-        """(1, N, 2) float32 of [u, v] for `keys`, in that order; a missing key raises
+        """(1, N, 2) float64 of [u, v] for `keys`, in that order; a missing key raises
         KeyError exactly as the reference's dict lookup does (:3270, :3307)."""
-        uv = np.empty((1, len(keys), 2), dtype=np.float32)
+        uv = np.empty((1, len(keys), 2), dtype=np.float64)
         for i, k in enumerate(keys):
             p = np.asarray(np_point_image_dict[k], dtype=np.float64).reshape(-1)
             uv[0, i, 0] = p[0]
@@ -121,7 +122,7 @@ class PNP_SOLVER(object):
     @staticmethod
     def _pattern_array(np_point_3d_dict, keys):
         return np.array([np.asarray(np_point_3d_dict[k], dtype=np.float64).reshape(3) for k in keys],
-                        dtype=np.float32)
+                        dtype=np.float64)
 
     def _finish(self, out):
         """Device result (batch of one) -> the reference's 7-tuple, with its side effects

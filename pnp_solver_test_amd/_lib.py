@@ -29,7 +29,9 @@ PTR_DEVICE = 1
 #: every symbol include/pnp_hip.h declares
 EXPORTS = (
     "pnp_qeif_default_params", "pnp_device_count", "pnp_init", "pnp_qeif_batch_f32",
-    "pnp_dlt_batch_f32", "pnp_euler_deg_f32", "pnp_qeif_multi_batch_f32", "pnp_project_batch_f64", "pnp_lm12_batch_f32",
+    "pnp_dlt_batch_f32", "pnp_lm12_batch_f32", "pnp_euler_deg_f32", "pnp_qeif_multi_batch_f32",
+    "pnp_qeif_batch_f64", "pnp_dlt_batch_f64", "pnp_lm12_batch_f64", "pnp_euler_deg_f64",
+    "pnp_qeif_multi_batch_f64", "pnp_project_batch_f64",
     "pnp_set_lanes_per_problem", "pnp_get_lanes_per_problem", "pnp_max_points",
     "pnp_last_error", "pnp_version",
 )
@@ -72,17 +74,17 @@ def load():
     lib.pnp_device_count.restype = ctypes.c_int
     lib.pnp_init.argtypes = [ctypes.c_int]
     lib.pnp_init.restype = ctypes.c_int
-    lib.pnp_qeif_batch_f32.argtypes = [vp, vp, i64, dp, i64, i32, pp, vp, vp, vp, vp, vp, i32, vp]
-    lib.pnp_qeif_batch_f32.restype = ctypes.c_int
-    lib.pnp_dlt_batch_f32.argtypes = [vp, vp, i64, dp, i64, i32, i32, vp, vp, vp, vp, i32, vp]
-    lib.pnp_dlt_batch_f32.restype = ctypes.c_int
-    lib.pnp_lm12_batch_f32.argtypes = [vp, vp, i64, dp, i64, i32, ctypes.c_double, i32, vp, vp, vp, vp, i32, vp]
-    lib.pnp_lm12_batch_f32.restype = ctypes.c_int
-    lib.pnp_euler_deg_f32.argtypes = [vp, i64, vp, i32, vp]
-    lib.pnp_euler_deg_f32.restype = ctypes.c_int
-    lib.pnp_qeif_multi_batch_f32.argtypes = [vp, vp, i32, dp, i64, i32, pp, vp, vp, vp, vp, vp, vp, i32, vp]
-    lib.pnp_qeif_multi_batch_f32.restype = ctypes.c_int
-    lib.pnp_project_batch_f64.argtypes = [vp, vp, vp, i64, dp, i64, i32, ctypes.c_double, vp, i32, vp]
+    for sfx in ("f32", "f64"):      # the two flavours share their signatures up to the element type
+        for name, args in (
+                ("pnp_qeif_batch_", [vp, vp, i64, dp, i64, i32, pp, vp, vp, vp, vp, vp, i32, vp]),
+                ("pnp_dlt_batch_", [vp, vp, i64, dp, i64, i32, i32, vp, vp, vp, vp, i32, vp]),
+                ("pnp_lm12_batch_", [vp, vp, i64, dp, i64, i32, ctypes.c_double, i32, vp, vp, vp, vp, i32, vp]),
+                ("pnp_euler_deg_", [vp, i64, vp, i32, vp]),
+                ("pnp_qeif_multi_batch_", [vp, vp, i32, dp, i64, i32, pp, vp, vp, vp, vp, vp, vp, i32, vp])):
+            fn = getattr(lib, name + sfx)
+            fn.argtypes = args
+            fn.restype = ctypes.c_int
+    lib.pnp_project_batch_f64.argtypes = [vp, vp, vp, i64, dp, i64, i32, ctypes.c_double, vp, i32, i32, vp]
     lib.pnp_project_batch_f64.restype = ctypes.c_int
     lib.pnp_set_lanes_per_problem.argtypes = [i32]
     lib.pnp_set_lanes_per_problem.restype = ctypes.c_int

@@ -44,11 +44,23 @@ def _shapes(uv_shape, xyz_shape):
                      % (B, N, tuple(xyz_shape)))
 
 
+def _np_dtype(uv, dtype):
+    """Element type of a call: an explicit `dtype`, else float64 if `uv` already is float64
+    (NumPy array or torch tensor), else float32."""
+    if dtype is None:
+        name = str(getattr(uv, "dtype", "")).replace("torch.", "")
+        return np.dtype(np.float64 if name == "float64" else np.float32)
+    dtype = np.dtype(str(dtype).replace("torch.", "") if type(dtype).__module__ == "torch" else dtype)
+    if dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+        raise TypeError("dtype must be float32 or float64, got %s" % dtype)
+    return dtype
+
+
 def solve_pnp_batch(uv, xyz, K, *, method="qeif", params=None, num_it=None, want_rpy=True,
-                    patterns=None, lm_lambda=1e-5):
+                    patterns=None, lm_lambda=1e-5, dtype=None):
     """Solve B independent PnP problems.
 
-    uv       (B, N, 2) float32 pixel coordinates
+    uv       (B, N, 2) pixel coordinates, float32 or float64
     xyz      (N, 3) pattern shared by all problems, or (B, N, 3) one pattern per problem
     K        (3, 3) camera matrix (float64, host)
     method   "qeif": quaternion information filter, the reference's live solver
@@ -62,10 +74,14 @@ def solve_pnp_batch(uv, xyz, K, *, method="qeif", params=None, num_it=None, want
     patterns optional (P, N, 3): QEIF against P shared patterns, keeping per problem the first
              with the smallest residual (the pattern loop of solve_pnp, :166-199); `xyz` is
              then ignored and the result gains "pattern_id"
+    dtype    element type of the arrays handed to the kernels and of the results: float32
+             (half the bytes) or float64 (the reference's dtype; agrees with it to float64
+             round-off).  None follows `uv`: float64 if it is float64, float32 otherwise.
+             The arithmetic is float64 either way.
 
     Returns a dict: R (B,3,3), t (B,3), t3 (B,), res_norm (B,), rpy_deg (B,3) = roll, yaw, pitch
-    in the reference's tuple order (if want_rpy), iters (B,) int32 (QEIF only).  Arrays are
-    float32 of the same kind (NumPy / torch on the same device) as `uv`.
+    in the reference's tuple order (if want_rpy), iters (B,) int32 (QEIF only).  Arrays are of
+    the same kind (NumPy / torch on the same device) as `uv`.
     """
     if method not in METHODS:
         raise ValueError("method must be one of %s" % (METHODS,))
@@ -76,24 +92,24 @@ def solve_pnp_batch(uv, xyz, K, *, method="qeif", params=None, num_it=None, want
     lib = _lib.load()
     Kc = _lib.k_array(K)
     extra = (num_it, float(lm_lambda))
+    ft = _np_dtype(uv, dtype)
     if _is_torch(uv):
-        return _solve_torch(lib, uv, xyz, Kc, method, params, extra, want_rpy, patterns)
-    return _solve_numpy(lib, uv, xyz, Kc, method, params, extra, want_rpy, patterns)
+        return _solve_torch(lib, uv, xyz, Kc, method, params, extra, want_rpy, patterns, ft)
+    return _solve_numpy(lib, uv, xyz, Kc, method, params, extra, want_rpy, patterns, ft)
 
 
-def _solve_numpy(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns):
-    uv = np.ascontiguousarray(uv, dtype=np.float32)
+def _solve_numpy(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, ft):
+    uv = np.ascontiguousarray(uv, dtype=ft)
     src = patterns if patterns is not None else xyz
-    src = np.ascontiguousarray(src, dtype=np.float32)
+    src = np.ascontiguousarray(src, dtype=ft)
     if patterns is not None:
         if src.ndim != 3 or src.shape[1:] != (uv.shape[1], 3):
             raise ValueError("patterns must have shape (P, N, 3)")
         B, N, stride, n_pat = int(uv.shape[0]), int(uv.shape[1]), 0, int(src.shape[0])
     else:
         B, N, stride, n_pat = _shapes(uv.shape, src.shape)
-    out = dict(R=np.empty((B, 3, 3), np.float32), t=np.empty((B, 3), np.float32),
-               res_norm=np.empty(B, np.float32))
-    rpy = np.empty((B, 3), np.float32) if want_rpy else None
+    out = dict(R=np.empty((B, 3, 3), ft), t=np.empty((B, 3), ft), res_norm=np.empty(B, ft))
+    rpy = np.empty((B, 3), ft) if want_rpy else None
     iters = np.empty(B, np.int32) if method == "qeif" else None
     pid = np.empty(B, np.int32) if patterns is not None else None
 
@@ -102,7 +118,7 @@ def _solve_numpy(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns):
 
     _call(lib, method, ptr(uv), ptr(src), stride, n_pat, Kc, B, N, params, num_it, ptr(out["R"]),
           ptr(out["t"]), ptr(out["res_norm"]), ptr(iters), ptr(rpy), ptr(pid), _lib.PTR_HOST, None,
-          patterns is not None)
+          patterns is not None, ft)
     out["t3"] = out["t"][:, 2].copy()
     if rpy is not None:
         out["rpy_deg"] = rpy
@@ -113,17 +129,18 @@ def _solve_numpy(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns):
     return out
 
 
-def _solve_torch(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns):
+def _solve_torch(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, ft):
     import torch
+    tt = torch.float64 if ft == np.dtype(np.float64) else torch.float32
 
     if not uv.is_cuda:
         raise ValueError("torch inputs must live on a HIP device (got %s); pass NumPy arrays for "
                          "host memory" % uv.device)
     src = patterns if patterns is not None else xyz
     if not _is_torch(src):
-        src = torch.as_tensor(np.ascontiguousarray(src, dtype=np.float32), device=uv.device)
-    if uv.dtype != torch.float32 or src.dtype != torch.float32:
-        raise TypeError("uv and xyz must be float32 tensors")
+        src = torch.as_tensor(np.ascontiguousarray(src, dtype=ft), device=uv.device)
+    if uv.dtype != tt or src.dtype != tt:
+        raise TypeError("uv and xyz must both be %s tensors (got %s and %s)" % (tt, uv.dtype, src.dtype))
     if src.device != uv.device:
         raise ValueError("uv and xyz must be on the same device")
     uv = uv.contiguous()
@@ -136,10 +153,10 @@ def _solve_torch(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns):
         B, N, stride, n_pat = _shapes(tuple(uv.shape), tuple(src.shape))
     dev = uv.device
     with torch.cuda.device(dev):
-        out = dict(R=torch.empty((B, 3, 3), dtype=torch.float32, device=dev),
-                   t=torch.empty((B, 3), dtype=torch.float32, device=dev),
-                   res_norm=torch.empty(B, dtype=torch.float32, device=dev))
-        rpy = torch.empty((B, 3), dtype=torch.float32, device=dev) if want_rpy else None
+        out = dict(R=torch.empty((B, 3, 3), dtype=tt, device=dev),
+                   t=torch.empty((B, 3), dtype=tt, device=dev),
+                   res_norm=torch.empty(B, dtype=tt, device=dev))
+        rpy = torch.empty((B, 3), dtype=tt, device=dev) if want_rpy else None
         iters = torch.empty(B, dtype=torch.int32, device=dev) if method == "qeif" else None
         pid = torch.empty(B, dtype=torch.int32, device=dev) if patterns is not None else None
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -149,7 +166,7 @@ def _solve_torch(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns):
 
         _call(lib, method, ptr(uv), ptr(src), stride, n_pat, Kc, B, N, params, num_it, ptr(out["R"]),
               ptr(out["t"]), ptr(out["res_norm"]), ptr(iters), ptr(rpy), ptr(pid), _lib.PTR_DEVICE,
-              stream, patterns is not None)
+              stream, patterns is not None, ft)
     out["t3"] = out["t"][:, 2]
     if rpy is not None:
         out["rpy_deg"] = rpy
@@ -161,40 +178,47 @@ def _solve_torch(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns):
 
 
 def _call(lib, method, uv, xyz, stride, n_pat, Kc, B, N, params, num_it, R, t, res, iters, rpy, pid,
-          kind, stream, multi):
+          kind, stream, multi, ft):
     pref = ctypes.byref(params) if params is not None else None
     num_it, lm_lambda = num_it
+    sfx = "f64" if ft == np.dtype(np.float64) else "f32"
     if method == "dlt":
-        rc = lib.pnp_dlt_batch_f32(uv, xyz, stride, Kc, B, N, int(num_it), R, t, res, rpy, kind, stream)
+        rc = getattr(lib, "pnp_dlt_batch_" + sfx)(uv, xyz, stride, Kc, B, N, int(num_it), R, t, res, rpy, kind,
+                                                  stream)
     elif method == "lm12":
-        rc = lib.pnp_lm12_batch_f32(uv, xyz, stride, Kc, B, N, lm_lambda, int(num_it), R, t, res, rpy, kind, stream)
+        rc = getattr(lib, "pnp_lm12_batch_" + sfx)(uv, xyz, stride, Kc, B, N, lm_lambda, int(num_it), R, t, res,
+                                                   rpy, kind, stream)
     elif multi:
-        rc = lib.pnp_qeif_multi_batch_f32(uv, xyz, n_pat, Kc, B, N, pref, R, t, res, iters, rpy, pid,
-                                          kind, stream)
+        rc = getattr(lib, "pnp_qeif_multi_batch_" + sfx)(uv, xyz, n_pat, Kc, B, N, pref, R, t, res, iters, rpy,
+                                                         pid, kind, stream)
     else:
-        rc = lib.pnp_qeif_batch_f32(uv, xyz, stride, Kc, B, N, pref, R, t, res, iters, rpy, kind, stream)
+        rc = getattr(lib, "pnp_qeif_batch_" + sfx)(uv, xyz, stride, Kc, B, N, pref, R, t, res, iters, rpy, kind,
+                                                   stream)
     _lib.check(rc)
 
 
 def euler_deg_batch(R):
-    """(B,3,3) or (B,9) float32 rotation matrices -> (B,3) roll, yaw, pitch in degrees
-    (get_Euler_from_rotation_matrix(..., is_degree=True), :4474-4517), on the device."""
+    """(B,3,3) or (B,9) rotation matrices -> (B,3) roll, yaw, pitch in degrees
+    (get_Euler_from_rotation_matrix(..., is_degree=True), :4474-4517), on the device.
+    float64 input gives float64 output; anything else is handled as float32."""
     lib = _lib.load()
+    ft = _np_dtype(R, None)
+    fn = lib.pnp_euler_deg_f64 if ft == np.dtype(np.float64) else lib.pnp_euler_deg_f32
     if _is_torch(R):
         import torch
-        if not R.is_cuda or R.dtype != torch.float32:
-            raise TypeError("R must be a float32 tensor on a HIP device")
+        if not R.is_cuda or R.dtype not in (torch.float32, torch.float64):
+            raise TypeError("R must be a float32 or float64 tensor on a HIP device")
         R = R.contiguous()
         B = R.numel() // 9
         with torch.cuda.device(R.device):
-            out = torch.empty((B, 3), dtype=torch.float32, device=R.device)
-            _lib.check(lib.pnp_euler_deg_f32(R.data_ptr(), B, out.data_ptr(), _lib.PTR_DEVICE,
-                                             torch.cuda.current_stream(R.device).cuda_stream))
+            out = torch.empty((B, 3), dtype=R.dtype, device=R.device)
+            _lib.check(fn(R.data_ptr(), B, out.data_ptr(), _lib.PTR_DEVICE,
+                          torch.cuda.current_stream(R.device).cuda_stream))
         return out
-    R = np.ascontiguousarray(R, dtype=np.float32)
+    R = np.ascontiguousarray(R, dtype=ft)
     B = R.size // 9
-    out = np.empty((B, 3), np.float32)
-    _lib.check(lib.pnp_euler_deg_f32(R.ctypes.data, B, out.ctypes.data, _lib.PTR_HOST, None))
+    out = np.empty((B, 3), ft)
+    _lib.check(fn(R.ctypes.data, B, out.ctypes.data, _lib.PTR_HOST, None))
     return out
 
 
@@ -226,13 +250,15 @@ def gather_results(local: dict, group=None) -> dict:
     return out
 
 
-def project_batch(roll, yaw, pitch, t, xyz, K, quantize_q=0.0, device=None):
+def project_batch(roll, yaw, pitch, t, xyz, K, quantize_q=0.0, device=None, dtype=np.float32):
     """Pixels of a pattern under B poses, on the device: the generator half of the reference's
     drivers (get_rotation_matrix_from_Euler :4442-4472 with angles in degrees, then
     perspective_projection :4532-4557).  roll, yaw, pitch (B,), t (B,3), xyz (N,3) or (B,N,3),
-    all float64; quantize_q = 1.0 reproduces is_quantized=True.  Returns uv (B,N,2) float32:
-    a NumPy array, or a torch tensor on `device` if one is given."""
+    all float64; quantize_q = 1.0 reproduces is_quantized=True.  Returns uv (B,N,2) of `dtype`
+    (float32 or float64): a NumPy array, or a torch tensor on `device` if one is given."""
     lib = _lib.load()
+    ft = _np_dtype(None, dtype)
+    is64 = int(ft == np.dtype(np.float64))
     rpy = np.ascontiguousarray(np.stack([roll, yaw, pitch], axis=1), dtype=np.float64)
     t = np.ascontiguousarray(t, dtype=np.float64)
     xyz = np.ascontiguousarray(xyz, dtype=np.float64)
@@ -247,17 +273,17 @@ def project_batch(roll, yaw, pitch, t, xyz, K, quantize_q=0.0, device=None):
         raise ValueError("xyz must have shape (N, 3) or (B, N, 3)")
     Kc = _lib.k_array(K)
     if device is None:
-        uv = np.empty((B, N, 2), np.float32)
+        uv = np.empty((B, N, 2), ft)
         _lib.check(lib.pnp_project_batch_f64(rpy.ctypes.data, t.ctypes.data, xyz.ctypes.data, stride, Kc, B, N,
-                                             float(quantize_q), uv.ctypes.data, _lib.PTR_HOST, None))
+                                             float(quantize_q), uv.ctypes.data, is64, _lib.PTR_HOST, None))
         return uv
     import torch
     dev = torch.device(device)
     with torch.cuda.device(dev):
         d_rpy, d_t, d_xyz = (torch.from_numpy(a).to(dev) for a in (rpy, t, xyz))
-        uv = torch.empty((B, N, 2), dtype=torch.float32, device=dev)
+        uv = torch.empty((B, N, 2), dtype=torch.float64 if is64 else torch.float32, device=dev)
         _lib.check(lib.pnp_project_batch_f64(d_rpy.data_ptr(), d_t.data_ptr(), d_xyz.data_ptr(), stride, Kc, B, N,
-                                             float(quantize_q), uv.data_ptr(), _lib.PTR_DEVICE,
+                                             float(quantize_q), uv.data_ptr(), is64, _lib.PTR_DEVICE,
                                              torch.cuda.current_stream(dev).cuda_stream))
         torch.cuda.current_stream(dev).synchronize()   # the float64 inputs above are temporaries
     return uv

@@ -97,30 +97,30 @@ int kinv_rows(const double K[9], pnp::KinvRows &ki)
     return PNP_OK;
 }
 
-size_t lds_bytes(int lpi, int N, bool per_problem_xyz, int n_patterns)
+size_t lds_bytes(int lpi, int N, bool per_problem_xyz, int n_patterns, size_t elem)
 {
-    const size_t pb = kBlock / lpi;
+    const size_t pb = (kBlock * sizeof(float) / elem) / lpi;   // pnp::kSolveBlock<T> / lpi
     const size_t uv = pb * 2 * N;
     const size_t xyz = per_problem_xyz ? pb * 3 * N : static_cast<size_t>(n_patterns) * 3 * N;
-    return (uv + xyz) * sizeof(float);
+    return (uv + xyz) * elem;
 }
 
 // Lanes per problem.  The floor is set by LDS: a workgroup's correspondences must fit the
 // budget.  Above the floor, more lanes per problem only pay when the batch is too small to
 // give every lane of the chip its own problem.
-int choose_lpi(int64_t B, int N, bool per_problem_xyz, int n_patterns)
+int choose_lpi(int64_t B, int N, bool per_problem_xyz, int n_patterns, size_t elem)
 {
     int forced = g_forced_lpi.load();
     int lpi = 1;
-    while (lpi < 64 && lds_bytes(lpi, N, per_problem_xyz, n_patterns) > kLdsBudget) lpi *= 2;
+    while (lpi < 64 && lds_bytes(lpi, N, per_problem_xyz, n_patterns, elem) > kLdsBudget) lpi *= 2;
     if (forced > 0) return forced > lpi ? forced : lpi;
     const int64_t chip_lanes = 256LL * 64 * 8;  // CUs x wave width x resident waves aimed for
     while (lpi < 64 && 2 * lpi <= N && B * lpi * 2 <= chip_lanes) lpi *= 2;
     return lpi;
 }
 
-int check_common(const float *uv, const float *xyz, int64_t xyz_stride, const double *K, int64_t B,
-                 int32_t N, const float *R_out, const float *t_out, int32_t ptr_kind)
+int check_common(const void *uv, const void *xyz, int64_t xyz_stride, const double *K, int64_t B,
+                 int32_t N, const void *R_out, const void *t_out, int32_t ptr_kind)
 {
     if (B < 0) return fail(PNP_E_ARG, "B = %lld is negative", static_cast<long long>(B));
     if (N < 1 || N > kMaxPoints) return fail(PNP_E_ARG, "N = %d outside [1, %d]", N, kMaxPoints);
@@ -151,35 +151,27 @@ pnp::QeifParams to_device_params(const pnp_qeif_params *p)
     return q;
 }
 
-// ---- launchers (device pointers only) ---------------------------------------------------------
+// ---- launchers (device pointers only; T = element type of the problem arrays) ----------------
 
-template <int LPI, int NCT>
-void launch_qeif_t(dim3 grid, size_t lds, hipStream_t s, const float *uv, const float *xyz,
-                   int64_t xyz_stride, int n_patterns, const pnp::KinvRows &ki, int64_t B, int N,
-                   const pnp::QeifParams &p, float *R, float *t, float *res, int32_t *iters,
-                   float *rpy, int32_t *pid)
-{
-    hipLaunchKernelGGL((pnp::qeif_kernel<LPI, NCT>), grid, dim3(kBlock), lds, s, uv, xyz, xyz_stride,
-                       n_patterns, ki, B, N, p, R, t, res, iters, rpy, pid);
-}
-
-int launch_qeif(hipStream_t s, const float *uv, const float *xyz, int64_t xyz_stride, int n_patterns,
-                const pnp::KinvRows &ki, int64_t B, int N, const pnp::QeifParams &p, float *R,
-                float *t, float *res, int32_t *iters, float *rpy, int32_t *pid)
+template <typename T>
+int launch_qeif(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, int n_patterns,
+                const pnp::KinvRows &ki, int64_t B, int N, const pnp::QeifParams &p, T *R, T *t, T *res,
+                int32_t *iters, T *rpy, int32_t *pid)
 {
     if (B == 0) return PNP_OK;
-    const int lpi = choose_lpi(B, N, xyz_stride != 0, n_patterns);
-    const size_t lds = lds_bytes(lpi, N, xyz_stride != 0, n_patterns);
+    const int lpi = choose_lpi(B, N, xyz_stride != 0, n_patterns, sizeof(T));
+    const size_t lds = lds_bytes(lpi, N, xyz_stride != 0, n_patterns, sizeof(T));
     if (lds > 64 * 1024)
         return fail(PNP_E_ARG, "N = %d with %d pattern(s) needs %zu bytes of LDS per workgroup (max 65536)",
                     N, n_patterns, lds);
-    const int64_t pb = kBlock / lpi;
+    constexpr int block = pnp::kSolveBlock<T>;
+    const int64_t pb = block / lpi;
     const int64_t nblk = (B + pb - 1) / pb;
     if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
     const dim3 grid(static_cast<unsigned>(nblk));
-#define PNP_Q(LPI_, NCT_)                                                                             \
-    launch_qeif_t<LPI_, NCT_>(grid, lds, s, uv, xyz, xyz_stride, n_patterns, ki, B, N, p, R, t, res, \
-                              iters, rpy, pid)
+#define PNP_Q(LPI_, NCT_)                                                                                 \
+    hipLaunchKernelGGL((pnp::qeif_kernel<LPI_, NCT_, T>), grid, dim3(block), lds, s, uv, xyz, xyz_stride, \
+                       n_patterns, ki, B, N, p, R, t, res, iters, rpy, pid)
     switch (lpi) {
     case 1:
         if (N == 6) PNP_Q(1, 6); else PNP_Q(1, 0);
@@ -196,29 +188,22 @@ int launch_qeif(hipStream_t s, const float *uv, const float *xyz, int64_t xyz_st
     return PNP_OK;
 }
 
-template <int LPI, int NCT>
-void launch_dlt_t(dim3 grid, size_t lds, hipStream_t s, const float *uv, const float *xyz,
-                  int64_t xyz_stride, const pnp::KinvRows &ki, int64_t B, int N, int num_it, float *R,
-                  float *t, float *res, float *rpy)
-{
-    hipLaunchKernelGGL((pnp::dlt_kernel<LPI, NCT>), grid, dim3(kBlock), lds, s, uv, xyz, xyz_stride, ki,
-                       B, N, num_it, R, t, res, rpy);
-}
-
-int launch_dlt(hipStream_t s, const float *uv, const float *xyz, int64_t xyz_stride,
-               const pnp::KinvRows &ki, int64_t B, int N, int num_it, float *R, float *t, float *res,
-               float *rpy)
+template <typename T>
+int launch_dlt(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, const pnp::KinvRows &ki,
+               int64_t B, int N, int num_it, T *R, T *t, T *res, T *rpy)
 {
     if (B == 0) return PNP_OK;
-    const int lpi = choose_lpi(B, N, xyz_stride != 0, 1);
-    const size_t lds = lds_bytes(lpi, N, xyz_stride != 0, 1);
+    const int lpi = choose_lpi(B, N, xyz_stride != 0, 1, sizeof(T));
+    const size_t lds = lds_bytes(lpi, N, xyz_stride != 0, 1, sizeof(T));
     if (lds > 64 * 1024) return fail(PNP_E_ARG, "N = %d needs %zu bytes of LDS per workgroup (max 65536)", N, lds);
-    const int64_t pb = kBlock / lpi;
+    constexpr int block = pnp::kSolveBlock<T>;
+    const int64_t pb = block / lpi;
     const int64_t nblk = (B + pb - 1) / pb;
     if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
     const dim3 grid(static_cast<unsigned>(nblk));
-#define PNP_D(LPI_, NCT_) \
-    launch_dlt_t<LPI_, NCT_>(grid, lds, s, uv, xyz, xyz_stride, ki, B, N, num_it, R, t, res, rpy)
+#define PNP_D(LPI_, NCT_)                                                                                \
+    hipLaunchKernelGGL((pnp::dlt_kernel<LPI_, NCT_, T>), grid, dim3(block), lds, s, uv, xyz, xyz_stride, \
+                       ki, B, N, num_it, R, t, res, rpy)
     switch (lpi) {
     case 1:
         if (N == 6) PNP_D(1, 6); else PNP_D(1, 0);
@@ -235,20 +220,38 @@ int launch_dlt(hipStream_t s, const float *uv, const float *xyz, int64_t xyz_str
     return PNP_OK;
 }
 
+template <typename T>
+int launch_lm12(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, const pnp::KinvRows &ki,
+                int64_t B, int N, double lambda, int num_it, T *R, T *t, T *res, T *rpy)
+{
+    if (B == 0) return PNP_OK;
+    const size_t pb = pnp::kLmBlock;
+    const size_t lds = (pb * 2 * N + (xyz_stride ? pb * 3 * N : static_cast<size_t>(3) * N)) * sizeof(T);
+    if (lds > static_cast<size_t>(kLdsBudget))
+        return fail(PNP_E_ARG, "N = %d needs %zu bytes of LDS per workgroup in the LM solver (max %d)", N, lds,
+                    kLdsBudget);
+    const int64_t nblk = (B + pnp::kLmBlock - 1) / pnp::kLmBlock;
+    if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
+    hipLaunchKernelGGL((pnp::lm12_kernel<T>), dim3(static_cast<unsigned>(nblk)), dim3(pnp::kLmBlock), lds, s, uv,
+                       xyz, xyz_stride, ki, B, N, lambda, num_it, R, t, res, rpy);
+    HIP_TRY(hipGetLastError());
+    return PNP_OK;
+}
+
 // ---- host-pointer wrapper ----------------------------------------------------------------------
 
+template <typename T>
 struct SolveIO {
-    const float *uv;
-    const float *xyz;
-    float *R, *t, *res, *rpy;
+    const T *uv;
+    const T *xyz;
+    T *R, *t, *res, *rpy;
     int32_t *iters, *pid;
 };
 
 // Copies the inputs of a host-pointer call to the device, runs `run` on device pointers and
 // copies the requested outputs back.  Synchronises the stream before returning.
-template <typename Run>
-int with_host_staging(hipStream_t s, int64_t B, int32_t N, size_t xyz_floats, const SolveIO &h,
-                      Run run)
+template <typename T, typename Run>
+int with_host_staging(hipStream_t s, int64_t B, int32_t N, size_t xyz_elems, const SolveIO<T> &h, Run run)
 {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
@@ -256,32 +259,204 @@ int with_host_staging(hipStream_t s, int64_t B, int32_t N, size_t xyz_floats, co
     Staging &st = g_staging[dev];
     std::lock_guard<std::mutex> lock(st.mu);
     const size_t nB = static_cast<size_t>(B);
-    const size_t total = 256 * 10 + (nB * 2 * N + xyz_floats + nB * (9 + 3 + 1 + 3)) * sizeof(float) +
+    const size_t total = 256 * 10 + (nB * 2 * N + xyz_elems + nB * (9 + 3 + 1 + 3)) * sizeof(T) +
                          2 * nB * sizeof(int32_t);
     int rc = staging_reserve(st, total);
     if (rc) return rc;
     Carver c(st.buf);
-    SolveIO d;
-    float *d_uv = c.take<float>(nB * 2 * N);
-    float *d_xyz = c.take<float>(xyz_floats);
+    SolveIO<T> d;
+    T *d_uv = c.take<T>(nB * 2 * N);
+    T *d_xyz = c.take<T>(xyz_elems);
     d.uv = d_uv;
     d.xyz = d_xyz;
-    d.R = c.take<float>(nB * 9);
-    d.t = c.take<float>(nB * 3);
-    d.res = c.take<float>(nB);
-    d.rpy = h.rpy ? c.take<float>(nB * 3) : nullptr;
+    d.R = c.take<T>(nB * 9);
+    d.t = c.take<T>(nB * 3);
+    d.res = c.take<T>(nB);
+    d.rpy = h.rpy ? c.take<T>(nB * 3) : nullptr;
     d.iters = h.iters ? c.take<int32_t>(nB) : nullptr;
     d.pid = h.pid ? c.take<int32_t>(nB) : nullptr;
-    HIP_TRY(hipMemcpyAsync(d_uv, h.uv, nB * 2 * N * sizeof(float), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_xyz, h.xyz, xyz_floats * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_uv, h.uv, nB * 2 * N * sizeof(T), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_xyz, h.xyz, xyz_elems * sizeof(T), hipMemcpyHostToDevice, s));
     rc = run(d);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(h.R, d.R, nB * 9 * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(h.t, d.t, nB * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (h.res) HIP_TRY(hipMemcpyAsync(h.res, d.res, nB * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (h.rpy) HIP_TRY(hipMemcpyAsync(h.rpy, d.rpy, nB * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h.R, d.R, nB * 9 * sizeof(T), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h.t, d.t, nB * 3 * sizeof(T), hipMemcpyDeviceToHost, s));
+    if (h.res) HIP_TRY(hipMemcpyAsync(h.res, d.res, nB * sizeof(T), hipMemcpyDeviceToHost, s));
+    if (h.rpy) HIP_TRY(hipMemcpyAsync(h.rpy, d.rpy, nB * 3 * sizeof(T), hipMemcpyDeviceToHost, s));
     if (h.iters) HIP_TRY(hipMemcpyAsync(h.iters, d.iters, nB * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     if (h.pid) HIP_TRY(hipMemcpyAsync(h.pid, d.pid, nB * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return PNP_OK;
+}
+
+// ---- entry-point bodies, shared by the float32 and float64 flavours -----------------------------
+
+template <typename T>
+int qeif_impl(const T *uv, const T *xyz, int64_t xyz_stride, int32_t n_patterns, const double K[9], int64_t B,
+              int32_t N, const pnp_qeif_params *p, T *R_out, T *t_out, T *res_out, int32_t *iters_out,
+              T *rpy_out, int32_t *pid_out, int32_t ptr_kind, void *hip_stream)
+{
+    g_err[0] = 0;
+    int rc = check_common(uv, xyz, xyz_stride, K, B, N, R_out, t_out, ptr_kind);
+    if (rc) return rc;
+    if (n_patterns < 1) return fail(PNP_E_ARG, "n_patterns = %d must be >= 1", n_patterns);
+    if (p && (p->max_it < 1)) return fail(PNP_E_ARG, "max_it = %d must be >= 1", p->max_it);
+    pnp::KinvRows ki;
+    rc = kinv_rows(K, ki);
+    if (rc) return rc;
+    const pnp::QeifParams q = to_device_params(p);
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (B == 0) return PNP_OK;
+    if (ptr_kind == PNP_PTR_DEVICE)
+        return launch_qeif<T>(s, uv, xyz, xyz_stride, n_patterns, ki, B, N, q, R_out, t_out, res_out, iters_out,
+                              rpy_out, pid_out);
+    if (xyz_stride != 0 && xyz_stride != 3 * static_cast<int64_t>(N))
+        return fail(PNP_E_ARG, "host-pointer calls take xyz_problem_stride 0 or 3*N only");
+    const size_t xyz_elems = xyz_stride ? static_cast<size_t>(B) * 3 * N : static_cast<size_t>(n_patterns) * 3 * N;
+    SolveIO<T> h{uv, xyz, R_out, t_out, res_out, rpy_out, iters_out, pid_out};
+    return with_host_staging<T>(s, B, N, xyz_elems, h, [&](const SolveIO<T> &d) {
+        return launch_qeif<T>(s, d.uv, d.xyz, xyz_stride, n_patterns, ki, B, N, q, d.R, d.t, d.res, d.iters, d.rpy,
+                              d.pid);
+    });
+}
+
+template <typename T>
+int dlt_impl(const T *uv, const T *xyz, int64_t xyz_stride, const double K[9], int64_t B, int32_t N,
+             int32_t num_it, T *R_out, T *t_out, T *res_out, T *rpy_out, int32_t ptr_kind, void *hip_stream)
+{
+    g_err[0] = 0;
+    int rc = check_common(uv, xyz, xyz_stride, K, B, N, R_out, t_out, ptr_kind);
+    if (rc) return rc;
+    if (num_it < 1) return fail(PNP_E_ARG, "num_it = %d must be >= 1", num_it);
+    pnp::KinvRows ki;
+    rc = kinv_rows(K, ki);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (B == 0) return PNP_OK;
+    if (ptr_kind == PNP_PTR_DEVICE)
+        return launch_dlt<T>(s, uv, xyz, xyz_stride, ki, B, N, num_it, R_out, t_out, res_out, rpy_out);
+    if (xyz_stride != 0 && xyz_stride != 3 * static_cast<int64_t>(N))
+        return fail(PNP_E_ARG, "host-pointer calls take xyz_problem_stride 0 or 3*N only");
+    const size_t xyz_elems = xyz_stride ? static_cast<size_t>(B) * 3 * N : static_cast<size_t>(3) * N;
+    SolveIO<T> h{uv, xyz, R_out, t_out, res_out, rpy_out, nullptr, nullptr};
+    return with_host_staging<T>(s, B, N, xyz_elems, h, [&](const SolveIO<T> &d) {
+        return launch_dlt<T>(s, d.uv, d.xyz, xyz_stride, ki, B, N, num_it, d.R, d.t, d.res, d.rpy);
+    });
+}
+
+template <typename T>
+int lm12_impl(const T *uv, const T *xyz, int64_t xyz_stride, const double K[9], int64_t B, int32_t N,
+              double lambda, int32_t num_it, T *R_out, T *t_out, T *res_out, T *rpy_out, int32_t ptr_kind,
+              void *hip_stream)
+{
+    g_err[0] = 0;
+    int rc = check_common(uv, xyz, xyz_stride, K, B, N, R_out, t_out, ptr_kind);
+    if (rc) return rc;
+    if (num_it < 1) return fail(PNP_E_ARG, "num_it = %d must be >= 1", num_it);
+    if (!(lambda >= 0.0)) return fail(PNP_E_ARG, "lambda must be >= 0");
+    pnp::KinvRows ki;
+    rc = kinv_rows(K, ki);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (B == 0) return PNP_OK;
+    if (ptr_kind == PNP_PTR_DEVICE)
+        return launch_lm12<T>(s, uv, xyz, xyz_stride, ki, B, N, lambda, num_it, R_out, t_out, res_out, rpy_out);
+    if (xyz_stride != 0 && xyz_stride != 3 * static_cast<int64_t>(N))
+        return fail(PNP_E_ARG, "host-pointer calls take xyz_problem_stride 0 or 3*N only");
+    const size_t xyz_elems = xyz_stride ? static_cast<size_t>(B) * 3 * N : static_cast<size_t>(3) * N;
+    SolveIO<T> h{uv, xyz, R_out, t_out, res_out, rpy_out, nullptr, nullptr};
+    return with_host_staging<T>(s, B, N, xyz_elems, h, [&](const SolveIO<T> &d) {
+        return launch_lm12<T>(s, d.uv, d.xyz, xyz_stride, ki, B, N, lambda, num_it, d.R, d.t, d.res, d.rpy);
+    });
+}
+
+template <typename T>
+int euler_impl(const T *R, int64_t B, T *rpy, int32_t ptr_kind, void *hip_stream)
+{
+    g_err[0] = 0;
+    if (B < 0) return fail(PNP_E_ARG, "B = %lld is negative", static_cast<long long>(B));
+    if (ptr_kind != PNP_PTR_HOST && ptr_kind != PNP_PTR_DEVICE)
+        return fail(PNP_E_ARG, "ptr_kind = %d is neither PNP_PTR_HOST nor PNP_PTR_DEVICE", ptr_kind);
+    if (B == 0) return PNP_OK;
+    if (!R || !rpy) return fail(PNP_E_ARG, "R and rpy must not be NULL");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const int64_t nblk = (B + kBlock - 1) / kBlock;
+    if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
+    const dim3 grid(static_cast<unsigned>(nblk));
+    if (ptr_kind == PNP_PTR_DEVICE) {
+        hipLaunchKernelGGL((pnp::euler_kernel<T>), grid, dim3(kBlock), 0, s, R, B, rpy);
+        HIP_TRY(hipGetLastError());
+        return PNP_OK;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(PNP_E_HIP, "device index %d out of range", dev);
+    Staging &st = g_staging[dev];
+    std::lock_guard<std::mutex> lock(st.mu);
+    const size_t nB = static_cast<size_t>(B);
+    int rc = staging_reserve(st, 1024 + nB * 12 * sizeof(T));
+    if (rc) return rc;
+    Carver c(st.buf);
+    T *d_R = c.take<T>(nB * 9);
+    T *d_rpy = c.take<T>(nB * 3);
+    HIP_TRY(hipMemcpyAsync(d_R, R, nB * 9 * sizeof(T), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL((pnp::euler_kernel<T>), grid, dim3(kBlock), 0, s, d_R, B, d_rpy);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rpy, d_rpy, nB * 3 * sizeof(T), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return PNP_OK;
+}
+
+template <typename T>
+int project_impl(const double *rpy_deg, const double *t, const double *xyz, int64_t xyz_stride, const double K[9],
+                 int64_t B, int32_t N, double quantize_q, T *uv_out, int32_t ptr_kind, void *hip_stream)
+{
+    g_err[0] = 0;
+    if (B < 0) return fail(PNP_E_ARG, "B = %lld is negative", static_cast<long long>(B));
+    if (N < 1) return fail(PNP_E_ARG, "N = %d must be >= 1", N);
+    if (!K) return fail(PNP_E_ARG, "K is NULL");
+    if (!(quantize_q >= 0.0)) return fail(PNP_E_ARG, "quantize_q must be >= 0");
+    if (ptr_kind != PNP_PTR_HOST && ptr_kind != PNP_PTR_DEVICE)
+        return fail(PNP_E_ARG, "ptr_kind = %d is neither PNP_PTR_HOST nor PNP_PTR_DEVICE", ptr_kind);
+    if (xyz_stride != 0 && xyz_stride < 3 * static_cast<int64_t>(N))
+        return fail(PNP_E_ARG, "xyz_problem_stride = %lld is neither 0 nor >= 3*N", static_cast<long long>(xyz_stride));
+    if (B == 0) return PNP_OK;
+    if (!rpy_deg || !t || !xyz || !uv_out) return fail(PNP_E_ARG, "rpy_deg, t, xyz and uv_out must not be NULL");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const int64_t nblk = (B + kBlock - 1) / kBlock;
+    if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
+    const dim3 grid(static_cast<unsigned>(nblk));
+    pnp::Mat3 Km;
+    for (int i = 0; i < 9; ++i) Km.m[i] = K[i];
+    if (ptr_kind == PNP_PTR_DEVICE) {
+        hipLaunchKernelGGL((pnp::project_kernel<T>), grid, dim3(kBlock), 0, s, rpy_deg, t, xyz, xyz_stride, Km, B, N,
+                           quantize_q, uv_out);
+        HIP_TRY(hipGetLastError());
+        return PNP_OK;
+    }
+    if (xyz_stride != 0 && xyz_stride != 3 * static_cast<int64_t>(N))
+        return fail(PNP_E_ARG, "host-pointer calls take xyz_problem_stride 0 or 3*N only");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(PNP_E_HIP, "device index %d out of range", dev);
+    Staging &st = g_staging[dev];
+    std::lock_guard<std::mutex> lock(st.mu);
+    const size_t nB = static_cast<size_t>(B);
+    const size_t xyz_n = xyz_stride ? nB * 3 * N : static_cast<size_t>(3) * N;
+    int rc = staging_reserve(st, 2048 + (nB * 6 + xyz_n + 16) * sizeof(double) + nB * 2 * N * sizeof(T));
+    if (rc) return rc;
+    Carver c(st.buf);
+    double *d_rpy = c.take<double>(nB * 3);
+    double *d_t = c.take<double>(nB * 3);
+    double *d_xyz = c.take<double>(xyz_n);
+    T *d_uv = c.take<T>(nB * 2 * N);
+    HIP_TRY(hipMemcpyAsync(d_rpy, rpy_deg, nB * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_t, t, nB * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_xyz, xyz, xyz_n * sizeof(double), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL((pnp::project_kernel<T>), grid, dim3(kBlock), 0, s, d_rpy, d_t, d_xyz, xyz_stride, Km, B, N,
+                       quantize_q, d_uv);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(uv_out, d_uv, nB * 2 * N * sizeof(T), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return PNP_OK;
 }
@@ -326,214 +501,100 @@ int pnp_init(int device)
     return PNP_OK;
 }
 
-int pnp_qeif_multi_batch_f32(const float *uv, const float *xyz, int32_t n_patterns, const double K[9],
-                             int64_t B, int32_t N, const pnp_qeif_params *p, float *R_out,
-                             float *t_out, float *res_out, int32_t *iters_out, float *rpy_out,
-                             int32_t *pattern_id_out, int32_t ptr_kind, void *hip_stream)
-{
-    g_err[0] = 0;
-    int rc = check_common(uv, xyz, 0, K, B, N, R_out, t_out, ptr_kind);
-    if (rc) return rc;
-    if (n_patterns < 1) return fail(PNP_E_ARG, "n_patterns = %d must be >= 1", n_patterns);
-    if (p && (p->max_it < 1)) return fail(PNP_E_ARG, "max_it = %d must be >= 1", p->max_it);
-    pnp::KinvRows ki;
-    rc = kinv_rows(K, ki);
-    if (rc) return rc;
-    const pnp::QeifParams q = to_device_params(p);
-    hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    if (B == 0) return PNP_OK;
-    if (ptr_kind == PNP_PTR_DEVICE)
-        return launch_qeif(s, uv, xyz, 0, n_patterns, ki, B, N, q, R_out, t_out, res_out, iters_out,
-                           rpy_out, pattern_id_out);
-    SolveIO h{uv, xyz, R_out, t_out, res_out, rpy_out, iters_out, pattern_id_out};
-    return with_host_staging(s, B, N, static_cast<size_t>(n_patterns) * 3 * N, h, [&](const SolveIO &d) {
-        return launch_qeif(s, d.uv, d.xyz, 0, n_patterns, ki, B, N, q, d.R, d.t, d.res, d.iters, d.rpy, d.pid);
-    });
-}
+// ---- float32 problem arrays ----------------------------------------------------------------------
 
 int pnp_qeif_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_stride, const double K[9],
                        int64_t B, int32_t N, const pnp_qeif_params *p, float *R_out, float *t_out,
-                       float *res_out, int32_t *iters_out, float *rpy_out, int32_t ptr_kind,
-                       void *hip_stream)
+                       float *res_out, int32_t *iters_out, float *rpy_out, int32_t ptr_kind, void *hip_stream)
 {
-    g_err[0] = 0;
-    int rc = check_common(uv, xyz, xyz_problem_stride, K, B, N, R_out, t_out, ptr_kind);
-    if (rc) return rc;
-    if (p && (p->max_it < 1)) return fail(PNP_E_ARG, "max_it = %d must be >= 1", p->max_it);
-    pnp::KinvRows ki;
-    rc = kinv_rows(K, ki);
-    if (rc) return rc;
-    const pnp::QeifParams q = to_device_params(p);
-    hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    if (B == 0) return PNP_OK;
-    if (ptr_kind == PNP_PTR_DEVICE)
-        return launch_qeif(s, uv, xyz, xyz_problem_stride, 1, ki, B, N, q, R_out, t_out, res_out,
-                           iters_out, rpy_out, nullptr);
-    if (xyz_problem_stride != 0 && xyz_problem_stride != 3 * static_cast<int64_t>(N))
-        return fail(PNP_E_ARG, "host-pointer calls take xyz_problem_stride 0 or 3*N only");
-    const size_t xyz_floats = xyz_problem_stride ? static_cast<size_t>(B) * 3 * N : static_cast<size_t>(3) * N;
-    SolveIO h{uv, xyz, R_out, t_out, res_out, rpy_out, iters_out, nullptr};
-    return with_host_staging(s, B, N, xyz_floats, h, [&](const SolveIO &d) {
-        return launch_qeif(s, d.uv, d.xyz, xyz_problem_stride, 1, ki, B, N, q, d.R, d.t, d.res, d.iters,
-                           d.rpy, nullptr);
-    });
+    return qeif_impl<float>(uv, xyz, xyz_problem_stride, 1, K, B, N, p, R_out, t_out, res_out, iters_out, rpy_out,
+                            nullptr, ptr_kind, hip_stream);
 }
 
-int pnp_dlt_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_stride, const double K[9],
-                      int64_t B, int32_t N, int32_t num_it, float *R_out, float *t_out, float *res_out,
-                      float *rpy_out, int32_t ptr_kind, void *hip_stream)
+int pnp_qeif_multi_batch_f32(const float *uv, const float *xyz, int32_t n_patterns, const double K[9], int64_t B,
+                             int32_t N, const pnp_qeif_params *p, float *R_out, float *t_out, float *res_out,
+                             int32_t *iters_out, float *rpy_out, int32_t *pattern_id_out, int32_t ptr_kind,
+                             void *hip_stream)
 {
-    g_err[0] = 0;
-    int rc = check_common(uv, xyz, xyz_problem_stride, K, B, N, R_out, t_out, ptr_kind);
-    if (rc) return rc;
-    if (num_it < 1) return fail(PNP_E_ARG, "num_it = %d must be >= 1", num_it);
-    pnp::KinvRows ki;
-    rc = kinv_rows(K, ki);
-    if (rc) return rc;
-    hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    if (B == 0) return PNP_OK;
-    if (ptr_kind == PNP_PTR_DEVICE)
-        return launch_dlt(s, uv, xyz, xyz_problem_stride, ki, B, N, num_it, R_out, t_out, res_out, rpy_out);
-    if (xyz_problem_stride != 0 && xyz_problem_stride != 3 * static_cast<int64_t>(N))
-        return fail(PNP_E_ARG, "host-pointer calls take xyz_problem_stride 0 or 3*N only");
-    const size_t xyz_floats = xyz_problem_stride ? static_cast<size_t>(B) * 3 * N : static_cast<size_t>(3) * N;
-    SolveIO h{uv, xyz, R_out, t_out, res_out, rpy_out, nullptr, nullptr};
-    return with_host_staging(s, B, N, xyz_floats, h, [&](const SolveIO &d) {
-        return launch_dlt(s, d.uv, d.xyz, xyz_problem_stride, ki, B, N, num_it, d.R, d.t, d.res, d.rpy);
-    });
+    return qeif_impl<float>(uv, xyz, 0, n_patterns, K, B, N, p, R_out, t_out, res_out, iters_out, rpy_out,
+                            pattern_id_out, ptr_kind, hip_stream);
 }
 
-static int launch_lm12(hipStream_t s, const float *uv, const float *xyz, int64_t xyz_stride,
-                       const pnp::KinvRows &ki, int64_t B, int N, double lambda, int num_it, float *R,
-                       float *t, float *res, float *rpy)
+int pnp_dlt_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_stride, const double K[9], int64_t B,
+                      int32_t N, int32_t num_it, float *R_out, float *t_out, float *res_out, float *rpy_out,
+                      int32_t ptr_kind, void *hip_stream)
 {
-    if (B == 0) return PNP_OK;
-    const size_t pb = pnp::kLmBlock;
-    const size_t lds = (pb * 2 * N + (xyz_stride ? pb * 3 * N : static_cast<size_t>(3) * N)) * sizeof(float);
-    if (lds > static_cast<size_t>(kLdsBudget))
-        return fail(PNP_E_ARG, "N = %d needs %zu bytes of LDS per workgroup in the LM solver (max %d)", N, lds,
-                    kLdsBudget);
-    const int64_t nblk = (B + pnp::kLmBlock - 1) / pnp::kLmBlock;
-    if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
-    hipLaunchKernelGGL(pnp::lm12_kernel, dim3(static_cast<unsigned>(nblk)), dim3(pnp::kLmBlock), lds, s, uv, xyz,
-                       xyz_stride, ki, B, N, lambda, num_it, R, t, res, rpy);
-    HIP_TRY(hipGetLastError());
-    return PNP_OK;
+    return dlt_impl<float>(uv, xyz, xyz_problem_stride, K, B, N, num_it, R_out, t_out, res_out, rpy_out, ptr_kind,
+                           hip_stream);
 }
 
-int pnp_lm12_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_stride, const double K[9],
-                       int64_t B, int32_t N, double lambda, int32_t num_it, float *R_out, float *t_out,
-                       float *res_out, float *rpy_out, int32_t ptr_kind, void *hip_stream)
+int pnp_lm12_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_stride, const double K[9], int64_t B,
+                       int32_t N, double lambda, int32_t num_it, float *R_out, float *t_out, float *res_out,
+                       float *rpy_out, int32_t ptr_kind, void *hip_stream)
 {
-    g_err[0] = 0;
-    int rc = check_common(uv, xyz, xyz_problem_stride, K, B, N, R_out, t_out, ptr_kind);
-    if (rc) return rc;
-    if (num_it < 1) return fail(PNP_E_ARG, "num_it = %d must be >= 1", num_it);
-    if (!(lambda >= 0.0)) return fail(PNP_E_ARG, "lambda must be >= 0");
-    pnp::KinvRows ki;
-    rc = kinv_rows(K, ki);
-    if (rc) return rc;
-    hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    if (B == 0) return PNP_OK;
-    if (ptr_kind == PNP_PTR_DEVICE)
-        return launch_lm12(s, uv, xyz, xyz_problem_stride, ki, B, N, lambda, num_it, R_out, t_out, res_out, rpy_out);
-    if (xyz_problem_stride != 0 && xyz_problem_stride != 3 * static_cast<int64_t>(N))
-        return fail(PNP_E_ARG, "host-pointer calls take xyz_problem_stride 0 or 3*N only");
-    const size_t xyz_floats = xyz_problem_stride ? static_cast<size_t>(B) * 3 * N : static_cast<size_t>(3) * N;
-    SolveIO h{uv, xyz, R_out, t_out, res_out, rpy_out, nullptr, nullptr};
-    return with_host_staging(s, B, N, xyz_floats, h, [&](const SolveIO &d) {
-        return launch_lm12(s, d.uv, d.xyz, xyz_problem_stride, ki, B, N, lambda, num_it, d.R, d.t, d.res, d.rpy);
-    });
+    return lm12_impl<float>(uv, xyz, xyz_problem_stride, K, B, N, lambda, num_it, R_out, t_out, res_out, rpy_out,
+                            ptr_kind, hip_stream);
 }
 
 int pnp_euler_deg_f32(const float *R, int64_t B, float *rpy, int32_t ptr_kind, void *hip_stream)
 {
-    g_err[0] = 0;
-    if (B < 0) return fail(PNP_E_ARG, "B = %lld is negative", static_cast<long long>(B));
-    if (ptr_kind != PNP_PTR_HOST && ptr_kind != PNP_PTR_DEVICE)
-        return fail(PNP_E_ARG, "ptr_kind = %d is neither PNP_PTR_HOST nor PNP_PTR_DEVICE", ptr_kind);
-    if (B == 0) return PNP_OK;
-    if (!R || !rpy) return fail(PNP_E_ARG, "R and rpy must not be NULL");
-    hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    const int64_t nblk = (B + kBlock - 1) / kBlock;
-    if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
-    if (ptr_kind == PNP_PTR_DEVICE) {
-        hipLaunchKernelGGL(pnp::euler_kernel, dim3(static_cast<unsigned>(nblk)), dim3(kBlock), 0, s, R, B, rpy);
-        HIP_TRY(hipGetLastError());
-        return PNP_OK;
-    }
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev < 0 || dev >= kMaxDevices) return fail(PNP_E_HIP, "device index %d out of range", dev);
-    Staging &st = g_staging[dev];
-    std::lock_guard<std::mutex> lock(st.mu);
-    const size_t nB = static_cast<size_t>(B);
-    int rc = staging_reserve(st, 1024 + nB * 12 * sizeof(float));
-    if (rc) return rc;
-    Carver c(st.buf);
-    float *d_R = c.take<float>(nB * 9);
-    float *d_rpy = c.take<float>(nB * 3);
-    HIP_TRY(hipMemcpyAsync(d_R, R, nB * 9 * sizeof(float), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(pnp::euler_kernel, dim3(static_cast<unsigned>(nblk)), dim3(kBlock), 0, s, d_R, B, d_rpy);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(rpy, d_rpy, nB * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return PNP_OK;
+    return euler_impl<float>(R, B, rpy, ptr_kind, hip_stream);
 }
 
-int pnp_project_batch_f64(const double *rpy_deg, const double *t, const double *xyz,
-                          int64_t xyz_problem_stride, const double K[9], int64_t B, int32_t N,
-                          double quantize_q, float *uv_out, int32_t ptr_kind, void *hip_stream)
+// ---- float64 problem arrays ----------------------------------------------------------------------
+
+int pnp_qeif_batch_f64(const double *uv, const double *xyz, int64_t xyz_problem_stride, const double K[9],
+                       int64_t B, int32_t N, const pnp_qeif_params *p, double *R_out, double *t_out,
+                       double *res_out, int32_t *iters_out, double *rpy_out, int32_t ptr_kind, void *hip_stream)
 {
-    g_err[0] = 0;
-    if (B < 0) return fail(PNP_E_ARG, "B = %lld is negative", static_cast<long long>(B));
-    if (N < 1) return fail(PNP_E_ARG, "N = %d must be >= 1", N);
-    if (!K) return fail(PNP_E_ARG, "K is NULL");
-    if (!(quantize_q >= 0.0)) return fail(PNP_E_ARG, "quantize_q must be >= 0");
-    if (ptr_kind != PNP_PTR_HOST && ptr_kind != PNP_PTR_DEVICE)
-        return fail(PNP_E_ARG, "ptr_kind = %d is neither PNP_PTR_HOST nor PNP_PTR_DEVICE", ptr_kind);
-    if (xyz_problem_stride != 0 && xyz_problem_stride < 3 * static_cast<int64_t>(N))
-        return fail(PNP_E_ARG, "xyz_problem_stride = %lld is neither 0 nor >= 3*N",
-                    static_cast<long long>(xyz_problem_stride));
-    if (B == 0) return PNP_OK;
-    if (!rpy_deg || !t || !xyz || !uv_out) return fail(PNP_E_ARG, "rpy_deg, t, xyz and uv_out must not be NULL");
-    hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    const int64_t nblk = (B + kBlock - 1) / kBlock;
-    if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
-    pnp::Mat3 Km;
-    for (int i = 0; i < 9; ++i) Km.m[i] = K[i];
-    if (ptr_kind == PNP_PTR_DEVICE) {
-        hipLaunchKernelGGL(pnp::project_kernel, dim3(static_cast<unsigned>(nblk)), dim3(kBlock), 0, s, rpy_deg, t,
-                           xyz, xyz_problem_stride, Km, B, N, quantize_q, uv_out);
-        HIP_TRY(hipGetLastError());
-        return PNP_OK;
-    }
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev < 0 || dev >= kMaxDevices) return fail(PNP_E_HIP, "device index %d out of range", dev);
-    Staging &st = g_staging[dev];
-    std::lock_guard<std::mutex> lock(st.mu);
-    const size_t nB = static_cast<size_t>(B);
-    if (xyz_problem_stride != 0 && xyz_problem_stride != 3 * static_cast<int64_t>(N))
-        return fail(PNP_E_ARG, "host-pointer calls take xyz_problem_stride 0 or 3*N only");
-    const size_t xyz_n = xyz_problem_stride ? nB * 3 * N : static_cast<size_t>(3) * N;
-    int rc = staging_reserve(st, 2048 + (nB * 6 + xyz_n + 16) * sizeof(double) + nB * 2 * N * sizeof(float));
-    if (rc) return rc;
-    Carver c(st.buf);
-    double *d_rpy = c.take<double>(nB * 3);
-    double *d_t = c.take<double>(nB * 3);
-    double *d_xyz = c.take<double>(xyz_n);
-    float *d_uv = c.take<float>(nB * 2 * N);
-    HIP_TRY(hipMemcpyAsync(d_rpy, rpy_deg, nB * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_t, t, nB * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_xyz, xyz, xyz_n * sizeof(double), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(pnp::project_kernel, dim3(static_cast<unsigned>(nblk)), dim3(kBlock), 0, s, d_rpy, d_t, d_xyz,
-                       xyz_problem_stride, Km, B, N, quantize_q, d_uv);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(uv_out, d_uv, nB * 2 * N * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return PNP_OK;
+    return qeif_impl<double>(uv, xyz, xyz_problem_stride, 1, K, B, N, p, R_out, t_out, res_out, iters_out, rpy_out,
+                             nullptr, ptr_kind, hip_stream);
 }
+
+int pnp_qeif_multi_batch_f64(const double *uv, const double *xyz, int32_t n_patterns, const double K[9], int64_t B,
+                             int32_t N, const pnp_qeif_params *p, double *R_out, double *t_out, double *res_out,
+                             int32_t *iters_out, double *rpy_out, int32_t *pattern_id_out, int32_t ptr_kind,
+                             void *hip_stream)
+{
+    return qeif_impl<double>(uv, xyz, 0, n_patterns, K, B, N, p, R_out, t_out, res_out, iters_out, rpy_out,
+                             pattern_id_out, ptr_kind, hip_stream);
+}
+
+int pnp_dlt_batch_f64(const double *uv, const double *xyz, int64_t xyz_problem_stride, const double K[9],
+                      int64_t B, int32_t N, int32_t num_it, double *R_out, double *t_out, double *res_out,
+                      double *rpy_out, int32_t ptr_kind, void *hip_stream)
+{
+    return dlt_impl<double>(uv, xyz, xyz_problem_stride, K, B, N, num_it, R_out, t_out, res_out, rpy_out, ptr_kind,
+                            hip_stream);
+}
+
+int pnp_lm12_batch_f64(const double *uv, const double *xyz, int64_t xyz_problem_stride, const double K[9],
+                       int64_t B, int32_t N, double lambda, int32_t num_it, double *R_out, double *t_out,
+                       double *res_out, double *rpy_out, int32_t ptr_kind, void *hip_stream)
+{
+    return lm12_impl<double>(uv, xyz, xyz_problem_stride, K, B, N, lambda, num_it, R_out, t_out, res_out, rpy_out,
+                             ptr_kind, hip_stream);
+}
+
+int pnp_euler_deg_f64(const double *R, int64_t B, double *rpy, int32_t ptr_kind, void *hip_stream)
+{
+    return euler_impl<double>(R, B, rpy, ptr_kind, hip_stream);
+}
+
+// ---- generator -----------------------------------------------------------------------------------
+
+int pnp_project_batch_f64(const double *rpy_deg, const double *t, const double *xyz, int64_t xyz_problem_stride,
+                          const double K[9], int64_t B, int32_t N, double quantize_q, void *uv_out,
+                          int32_t uv_is_f64, int32_t ptr_kind, void *hip_stream)
+{
+    if (uv_is_f64)
+        return project_impl<double>(rpy_deg, t, xyz, xyz_problem_stride, K, B, N, quantize_q,
+                                    static_cast<double *>(uv_out), ptr_kind, hip_stream);
+    return project_impl<float>(rpy_deg, t, xyz, xyz_problem_stride, K, B, N, quantize_q,
+                               static_cast<float *>(uv_out), ptr_kind, hip_stream);
+}
+
+// ---- tuning and introspection -----------------------------------------------------------------------
 
 int pnp_set_lanes_per_problem(int32_t lanes)
 {
@@ -547,13 +608,13 @@ int pnp_set_lanes_per_problem(int32_t lanes)
 int pnp_get_lanes_per_problem(int64_t B, int32_t N, int64_t xyz_problem_stride)
 {
     if (N < 1 || N > kMaxPoints) return fail(PNP_E_ARG, "N = %d outside [1, %d]", N, kMaxPoints);
-    return choose_lpi(B, N, xyz_problem_stride != 0, 1);
+    return choose_lpi(B, N, xyz_problem_stride != 0, 1, sizeof(float));
 }
 
 int pnp_max_points(void) { return kMaxPoints; }
 
 const char *pnp_last_error(void) { return g_err; }
 
-const char *pnp_version(void) { return "pnp_hip 0.1 (gfx950)"; }
+const char *pnp_version(void) { return "pnp_hip 0.2 (gfx950)"; }
 
 }  // extern "C"

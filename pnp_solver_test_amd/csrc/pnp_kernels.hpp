@@ -12,8 +12,8 @@
 // LPI = 64 is one wavefront per problem (latency-optimal for few, large problems);
 // LPI = 1 is one lane per problem (throughput-optimal for millions of six-point problems).
 //
-// All arithmetic is float64: inputs are float32 and are widened on load, outputs are
-// rounded to float32 once on store.
+// All arithmetic is float64.  The problem arrays are float32 (widened on load, results rounded
+// once on store) or float64; the entry points come in both flavours.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -22,6 +22,10 @@
 namespace pnp {
 
 constexpr int kBlock = 256;
+// Threads per workgroup of the solver kernels for element type T: 256 for float, 128 for double,
+// so that a workgroup's staged correspondences take the same LDS bytes either way.
+template <typename T>
+constexpr int kSolveBlock = kBlock * static_cast<int>(sizeof(float)) / static_cast<int>(sizeof(T));
 
 #ifndef PNP_QEIF_WAVES
 #define PNP_QEIF_WAVES 2  // minimum resident waves per SIMD the QEIF kernels are compiled for
@@ -241,15 +245,16 @@ __device__ __forceinline__ void euler_deg(const double (&R)[9], double &roll, do
 // staging: contiguous global range -> LDS, 16 bytes per lane when alignment allows
 // ------------------------------------------------------------------------------------------
 
-template <int BLOCK = kBlock>
-__device__ __forceinline__ void stage_floats(float *dst, const float *src, int count, int tid)
+template <int BLOCK = kBlock, typename T>
+__device__ __forceinline__ void stage_elems(T *dst, const T *src, int count, int tid)
 {
+    constexpr int per16 = 16 / static_cast<int>(sizeof(T));
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-        const int n4 = count >> 2;
-        const float4 *s4 = reinterpret_cast<const float4 *>(src);
-        float4 *d4 = reinterpret_cast<float4 *>(dst);
-        for (int i = tid; i < n4; i += BLOCK) d4[i] = s4[i];
-        for (int i = (n4 << 2) + tid; i < count; i += BLOCK) dst[i] = src[i];
+        const int n16 = count / per16;
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+        for (int i = tid; i < n16; i += BLOCK) d4[i] = s4[i];
+        for (int i = n16 * per16 + tid; i < count; i += BLOCK) dst[i] = src[i];
     } else {
         for (int i = tid; i < count; i += BLOCK) dst[i] = src[i];
     }
@@ -824,16 +829,20 @@ __device__ __forceinline__ void lm12_solve(const PointFetch &pts, int N, double 
 // kernels
 // ------------------------------------------------------------------------------------------
 
-// Point access into the workgroup's LDS image (float32 as loaded; widened on every use).
+// The kernels below are templated on the element type T of the problem arrays (float or
+// double): pixels, pattern, R, t, residual and angles are read and written as T, and all
+// arithmetic in between is double.
+
+// Point access into the workgroup's LDS image (stored as loaded; widened on every use).
+template <typename T>
 struct LdsPoints {
-    const float *uv;   // this problem's (N,2)
-    const float *xyz;  // this problem's (N,3)
+    const T *uv;   // this problem's (N,2)
+    const T *xyz;  // this problem's (N,3)
     KinvRows ki;
     __device__ __forceinline__ void operator()(int i, double &X, double &Y, double &Z, double &bx,
                                                double &by) const
     {
-        const float2 p = *reinterpret_cast<const float2 *>(uv + 2 * i);
-        const double u = static_cast<double>(p.x), v = static_cast<double>(p.y);
+        const double u = static_cast<double>(uv[2 * i]), v = static_cast<double>(uv[2 * i + 1]);
         bx = __builtin_fma(ki.a00, u, __builtin_fma(ki.a01, v, ki.a02));
         by = __builtin_fma(ki.a10, u, __builtin_fma(ki.a11, v, ki.a12));
         X = static_cast<double>(xyz[3 * i]);
@@ -846,12 +855,14 @@ struct LdsPoints {
 template <int NCT>
 struct RegPoints {
     double X[NCT], Y[NCT], Z[NCT], bx[NCT], by[NCT];
-    __device__ __forceinline__ explicit RegPoints(const LdsPoints &src)
+    template <typename Src>
+    __device__ __forceinline__ explicit RegPoints(const Src &src)
     {
 #pragma unroll
         for (int i = 0; i < NCT; ++i) src(i, X[i], Y[i], Z[i], bx[i], by[i]);
     }
-    __device__ __forceinline__ void set_pattern(const LdsPoints &src)
+    template <typename Src>
+    __device__ __forceinline__ void set_pattern(const Src &src)
     {
 #pragma unroll
         for (int i = 0; i < NCT; ++i) {
@@ -871,33 +882,35 @@ struct RegPoints {
 };
 
 // What a lane knows about its place in the workgroup after staging.
+template <typename T>
 struct Slot {
     int64_t problem;     // global problem index this lane works on
     bool store;          // this lane writes the problem's outputs
     int lane_in_group;   // 0..LPI-1
-    LdsPoints pts;       // view of the problem's points (pattern 0)
-    int xyz_step;        // floats from one shared pattern to the next in LDS (3N)
+    LdsPoints<T> pts;    // view of the problem's points (pattern 0)
+    int xyz_step;        // elements from one shared pattern to the next in LDS (3N)
 };
 
 // Stages the workgroup's problems into dynamic LDS and returns this lane's slot.
-// LDS layout: [uv of PB problems: PB*2N floats][xyz: PB*3N floats per-problem, or
-// n_patterns*3N floats when the patterns are shared by all problems]
-template <int LPI, int BLOCK = kBlock>
-__device__ __forceinline__ Slot stage_problems(float *lds, const float *uv, const float *xyz,
-                                               int64_t xyz_stride, int n_patterns,
-                                               const KinvRows &ki, int64_t B, int N)
+// LDS layout: [uv of PB problems: PB*2N elements][xyz: PB*3N elements per-problem, or
+// n_patterns*3N elements when the patterns are shared by all problems]
+template <int LPI, int BLOCK, typename T>
+__device__ __forceinline__ Slot<T> stage_problems(const T *uv, const T *xyz, int64_t xyz_stride,
+                                                  int n_patterns, const KinvRows &ki, int64_t B, int N)
 {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    T *lds = reinterpret_cast<T *>(lds_raw);
     constexpr int PB = BLOCK / LPI;
     const int tid = threadIdx.x;
     const int64_t first = static_cast<int64_t>(blockIdx.x) * PB;
     const int nprob = static_cast<int>(min(static_cast<int64_t>(PB), B - first));
-    float *s_uv = lds;
-    float *s_xyz = lds + PB * 2 * N;
-    stage_floats<BLOCK>(s_uv, uv + first * 2 * N, nprob * 2 * N, tid);
+    T *s_uv = lds;
+    T *s_xyz = lds + PB * 2 * N;
+    stage_elems<BLOCK>(s_uv, uv + first * 2 * N, nprob * 2 * N, tid);
     if (xyz_stride == 0) {
-        stage_floats<BLOCK>(s_xyz, xyz, n_patterns * 3 * N, tid);
+        stage_elems<BLOCK>(s_xyz, xyz, n_patterns * 3 * N, tid);
     } else if (xyz_stride == 3 * static_cast<int64_t>(N)) {
-        stage_floats<BLOCK>(s_xyz, xyz + first * xyz_stride, nprob * 3 * N, tid);
+        stage_elems<BLOCK>(s_xyz, xyz + first * xyz_stride, nprob * 3 * N, tid);
     } else {
         for (int i = tid; i < nprob * 3 * N; i += BLOCK) {
             const int g = i / (3 * N);
@@ -905,7 +918,7 @@ __device__ __forceinline__ Slot stage_problems(float *lds, const float *uv, cons
         }
     }
     __syncthreads();
-    Slot s;
+    Slot<T> s;
     int g = tid / LPI;
     s.lane_in_group = tid % LPI;
     s.store = (g < nprob) && (s.lane_in_group == 0);
@@ -918,36 +931,36 @@ __device__ __forceinline__ Slot stage_problems(float *lds, const float *uv, cons
     return s;
 }
 
-__device__ __forceinline__ void store_pose(int64_t problem, const double (&R)[9],
-                                           const double (&t)[3], float *R_out, float *t_out)
+template <typename T>
+__device__ __forceinline__ void store_pose(int64_t problem, const double (&R)[9], const double (&t)[3],
+                                           T *R_out, T *t_out)
 {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) R_out[problem * 9 + i] = static_cast<float>(R[i]);
+    for (int i = 0; i < 9; ++i) R_out[problem * 9 + i] = static_cast<T>(R[i]);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) t_out[problem * 3 + i] = static_cast<float>(t[i]);
+    for (int i = 0; i < 3; ++i) t_out[problem * 3 + i] = static_cast<T>(t[i]);
 }
 
-__device__ __forceinline__ void store_rpy(int64_t problem, const double (&R)[9], float *rpy_out)
+template <typename T>
+__device__ __forceinline__ void store_rpy(int64_t problem, const double (&R)[9], T *rpy_out)
 {
     double roll, yaw, pitch;
     euler_deg(R, roll, yaw, pitch);
-    rpy_out[problem * 3 + 0] = static_cast<float>(roll);
-    rpy_out[problem * 3 + 1] = static_cast<float>(yaw);
-    rpy_out[problem * 3 + 2] = static_cast<float>(pitch);
+    rpy_out[problem * 3 + 0] = static_cast<T>(roll);
+    rpy_out[problem * 3 + 1] = static_cast<T>(yaw);
+    rpy_out[problem * 3 + 2] = static_cast<T>(pitch);
 }
 
 // QEIF over B problems.  n_patterns > 1 (shared patterns only) solves every problem against
 // each pattern in turn and keeps the first one with the strictly smallest residual.
 // NCT > 0 requires LPI == 1 and N == NCT.
-template <int LPI, int NCT>
-__global__ __launch_bounds__(kBlock, PNP_QEIF_WAVES) void qeif_kernel(
-    const float *__restrict__ uv, const float *__restrict__ xyz, int64_t xyz_stride, int n_patterns,
-    KinvRows ki, int64_t B, int N, QeifParams p, float *__restrict__ R_out,
-    float *__restrict__ t_out, float *__restrict__ res_out, int32_t *__restrict__ iters_out,
-    float *__restrict__ rpy_out, int32_t *__restrict__ pattern_id_out)
+template <int LPI, int NCT, typename T>
+__global__ __launch_bounds__(kSolveBlock<T>, PNP_QEIF_WAVES) void qeif_kernel(
+    const T *__restrict__ uv, const T *__restrict__ xyz, int64_t xyz_stride, int n_patterns, KinvRows ki,
+    int64_t B, int N, QeifParams p, T *__restrict__ R_out, T *__restrict__ t_out, T *__restrict__ res_out,
+    int32_t *__restrict__ iters_out, T *__restrict__ rpy_out, int32_t *__restrict__ pattern_id_out)
 {
-    extern __shared__ __align__(16) float lds[];
-    Slot s = stage_problems<LPI>(lds, uv, xyz, xyz_stride, n_patterns, ki, B, N);
+    Slot<T> s = stage_problems<LPI, kSolveBlock<T>>(uv, xyz, xyz_stride, n_patterns, ki, B, N);
     double R[9], t[3], res;
     int iters, best = 0;
     if constexpr (NCT > 0) {
@@ -989,21 +1002,19 @@ __global__ __launch_bounds__(kBlock, PNP_QEIF_WAVES) void qeif_kernel(
     }
     if (s.store) {
         store_pose(s.problem, R, t, R_out, t_out);
-        if (res_out) res_out[s.problem] = static_cast<float>(res);
+        if (res_out) res_out[s.problem] = static_cast<T>(res);
         if (iters_out) iters_out[s.problem] = iters;
         if (rpy_out) store_rpy(s.problem, R, rpy_out);
         if (pattern_id_out) pattern_id_out[s.problem] = best;
     }
 }
 
-template <int LPI, int NCT>
-__global__ __launch_bounds__(kBlock) void dlt_kernel(
-    const float *__restrict__ uv, const float *__restrict__ xyz, int64_t xyz_stride, KinvRows ki,
-    int64_t B, int N, int num_it, float *__restrict__ R_out, float *__restrict__ t_out,
-    float *__restrict__ res_out, float *__restrict__ rpy_out)
+template <int LPI, int NCT, typename T>
+__global__ __launch_bounds__(kSolveBlock<T>) void dlt_kernel(
+    const T *__restrict__ uv, const T *__restrict__ xyz, int64_t xyz_stride, KinvRows ki, int64_t B, int N,
+    int num_it, T *__restrict__ R_out, T *__restrict__ t_out, T *__restrict__ res_out, T *__restrict__ rpy_out)
 {
-    extern __shared__ __align__(16) float lds[];
-    const Slot s = stage_problems<LPI>(lds, uv, xyz, xyz_stride, 1, ki, B, N);
+    const Slot<T> s = stage_problems<LPI, kSolveBlock<T>>(uv, xyz, xyz_stride, 1, ki, B, N);
     double R[9], t[3], res;
     if constexpr (NCT > 0) {
         const RegPoints<NCT> rp(s.pts);
@@ -1013,7 +1024,7 @@ __global__ __launch_bounds__(kBlock) void dlt_kernel(
     }
     if (s.store) {
         store_pose(s.problem, R, t, R_out, t_out);
-        if (res_out) res_out[s.problem] = static_cast<float>(res);
+        if (res_out) res_out[s.problem] = static_cast<T>(res);
         if (rpy_out) store_rpy(s.problem, R, rpy_out);
     }
 }
@@ -1021,18 +1032,18 @@ __global__ __launch_bounds__(kBlock) void dlt_kernel(
 constexpr int kLmBlock = 64;  // one wavefront per workgroup: the 12x12 system needs the whole register file
 
 // 12-state LM over B problems, one lane per problem.
+template <typename T>
 __global__ __launch_bounds__(kLmBlock) void lm12_kernel(
-    const float *__restrict__ uv, const float *__restrict__ xyz, int64_t xyz_stride, KinvRows ki,
-    int64_t B, int N, double lam, int num_it, float *__restrict__ R_out, float *__restrict__ t_out,
-    float *__restrict__ res_out, float *__restrict__ rpy_out)
+    const T *__restrict__ uv, const T *__restrict__ xyz, int64_t xyz_stride, KinvRows ki, int64_t B, int N,
+    double lam, int num_it, T *__restrict__ R_out, T *__restrict__ t_out, T *__restrict__ res_out,
+    T *__restrict__ rpy_out)
 {
-    extern __shared__ __align__(16) float lds[];
-    const Slot s = stage_problems<1, kLmBlock>(lds, uv, xyz, xyz_stride, 1, ki, B, N);
+    const Slot<T> s = stage_problems<1, kLmBlock>(uv, xyz, xyz_stride, 1, ki, B, N);
     double R[9], t[3], res;
     lm12_solve(s.pts, N, lam, num_it, R, t, res);
     if (s.store) {
         store_pose(s.problem, R, t, R_out, t_out);
-        if (res_out) res_out[s.problem] = static_cast<float>(res);
+        if (res_out) res_out[s.problem] = static_cast<T>(res);
         if (rpy_out) store_rpy(s.problem, R, rpy_out);
     }
 }
@@ -1040,10 +1051,11 @@ __global__ __launch_bounds__(kLmBlock) void lm12_kernel(
 // Synthetic-input generator: pose (roll, yaw, pitch in degrees; t) -> pixels of a pattern.
 // R = E_roll E_pitch E_yaw with the yaw sign flipped first; ray = K (R p + t); the ray is
 // divided by |ray_z| and, if q > 0, rounded half-to-even onto a grid of step q.
-// One lane per pose; float64 throughout, pixels stored as float32.
+// One lane per pose; float64 throughout, pixels stored as T.
+template <typename T>
 __global__ __launch_bounds__(kBlock) void project_kernel(
     const double *__restrict__ rpy_deg, const double *__restrict__ t, const double *__restrict__ xyz,
-    int64_t xyz_stride, Mat3 Kmat, int64_t B, int N, double q, float *__restrict__ uv_out)
+    int64_t xyz_stride, Mat3 Kmat, int64_t B, int N, double q, T *__restrict__ uv_out)
 {
     const int64_t b = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (b >= B) return;
@@ -1072,13 +1084,13 @@ __global__ __launch_bounds__(kBlock) void project_kernel(
             u = rint(u / q) * q;
             v = rint(v / q) * q;
         }
-        uv_out[(b * N + i) * 2] = static_cast<float>(u);
-        uv_out[(b * N + i) * 2 + 1] = static_cast<float>(v);
+        uv_out[(b * N + i) * 2] = static_cast<T>(u);
+        uv_out[(b * N + i) * 2 + 1] = static_cast<T>(v);
     }
 }
 
-__global__ __launch_bounds__(kBlock) void euler_kernel(const float *__restrict__ R_in, int64_t B,
-                                                       float *__restrict__ rpy_out)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void euler_kernel(const T *__restrict__ R_in, int64_t B, T *__restrict__ rpy_out)
 {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (i >= B) return;

@@ -11,10 +11,48 @@ import numpy as np
 F_CAMERA = 225.68717584155982                      # random_stress_test.py:103
 K_DEFAULT = np.array([[F_CAMERA, 0.0, 160.0], [0.0, F_CAMERA, 120.0], [0.0, 0.0, 1.0]])
 
-#: rows of the "Alexander" golden pattern (TEST_TOOLBOX.py:105-111) for the six landmarks
-#: solve_pnp uses, in its order (PNP_SOLVER_LIB.py:156)
-PATTERN6 = np.array([[0.032, 0.0, 0.0], [-0.032, 0.0, 0.0], [0.027, 0.070, 0.0],
-                     [-0.027, 0.070, 0.0], [-0.005, 0.0455, -0.03], [0.0, 0.12, 0.0]])
+#: the six landmarks solve_pnp uses, in its order (PNP_SOLVER_LIB.py:156)
+LM6_KEYS = ("eye_l_96", "eye_r_97", "mouse_l_76", "mouse_r_82", "nose_t_54", "chin_t_16")
+
+#: the two 15-landmark golden face patterns of the reference's drivers, metres, in the key order
+#: of TEST_TOOLBOX.get_golden_pattern (TEST_TOOLBOX.py:67-128)
+GOLDEN_PATTERNS = {
+    "Alexander": {
+        "eye_l_96": [0.032, 0.0, 0.0], "eye_r_97": [-0.032, 0.0, 0.0], "eye_c_51": [0.0, 0.0, -0.015],
+        "mouse_l_76": [0.027, 0.070, 0.0], "mouse_r_82": [-0.027, 0.070, 0.0],
+        "nose_t_54": [-0.005, 0.0455, -0.03], "chin_t_16": [0.0, 0.12, 0.0],
+        "brow_cl_35": [0.035, -0.0228, 0.0], "brow_il_37": [0.0135, -0.017, 0.0],
+        "brow_ir_42": [-0.0135, -0.017, 0.0], "brow_cr_44": [-0.035, -0.0228, 0.0],
+        "eye_lo_60": [0.047, 0.0, 0.005], "eye_li_64": [0.018, 0.0, 0.0],
+        "eye_ro_72": [-0.047, 0.0, 0.005], "eye_ri_68": [-0.018, 0.0, 0.0],
+    },
+    "Holly": {
+        "eye_l_96": [0.028, 0.0, 0.0], "eye_r_97": [-0.028, 0.0, 0.0], "eye_c_51": [0.0, 0.0, 0.0],
+        "mouse_l_76": [0.025, 0.060, 0.0], "mouse_r_82": [-0.025, 0.060, 0.0],
+        "nose_t_54": [0.0, 0.039, -0.03], "chin_t_16": [0.0, 0.098, 0.0],
+        "brow_cl_35": [0.035, -0.0228, 0.0], "brow_il_37": [0.0135, -0.017, 0.0],
+        "brow_ir_42": [-0.0135, -0.017, 0.0], "brow_cr_44": [-0.035, -0.0228, 0.0],
+        "eye_lo_60": [0.046, 0.0, 0.0], "eye_li_64": [0.01, 0.0, 0.0],
+        "eye_ro_72": [-0.046, 0.0, 0.0], "eye_ri_68": [-0.01, 0.0, 0.0],
+    },
+}
+
+
+def get_golden_pattern(pattern_name="Alexander"):
+    """dict {landmark: [x, y, z]} as the reference's get_golden_pattern returns it (any name other
+    than "Holly" yields "Alexander", as there)."""
+    src = GOLDEN_PATTERNS["Holly" if pattern_name == "Holly" else "Alexander"]
+    return {k: list(v) for k, v in src.items()}
+
+
+def pattern_rows(pattern_name="Alexander", keys=None):
+    """(N,3) float64 rows of a golden pattern for `keys` (default: all 15, in dict order)."""
+    src = GOLDEN_PATTERNS["Holly" if pattern_name == "Holly" else "Alexander"]
+    return np.array([src[k] for k in (keys or src)], dtype=np.float64)
+
+
+#: rows of "Alexander" for the six solver landmarks
+PATTERN6 = pattern_rows("Alexander", LM6_KEYS)
 
 
 def face68(seed: int = 0) -> np.ndarray:

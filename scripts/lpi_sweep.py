@@ -66,8 +66,7 @@ out["host_pointer_path_b1m"] = dict(ms_per_batch=dt * 1e3, solves_per_s=B / dt,
                                     note="pageable NumPy buffers: H2D 126 MB + kernel + D2H 59 MB, synchronous")
 
 # single-call latency through the drop-in class
-from oracle import pnp_oracle as po  # noqa: E402  (pattern tables only)
-s = pnp.PNP_SOLVER(K, [po.PATTERN_ALEXANDER])
+s = pnp.PNP_SOLVER(K, [synth.get_golden_pattern("Alexander")])
 R = s.get_rotation_matrix_from_Euler(15.0, 45.0, -15.0, is_degree=True)
 img = s.perspective_projection_golden_landmarks(R, np.array([[0.35], [0.35], [0.5]]), is_quantized=True)
 for _ in range(20):

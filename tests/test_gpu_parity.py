@@ -1,6 +1,9 @@
 """Parity of the HIP path (through the C ABI) with the oracle and the reference-generated
 golden vectors.  Needs an MI355X: run with `-m gpu`.
 
+The float64 flavour of the entry points is checked near the end of the file against the same
+golden vectors to 1e-9 (pure float64 round-off).
+
 Stated tolerances (float32 I/O, float64 arithmetic):
   rotation geodesic angle <= 1e-5 rad, |dt|/|t| <= 1e-4 against the REFERENCE (golden files;
   includes the float32 rounding of the pattern coordinates the device path applies);
@@ -657,3 +660,148 @@ def test_lm12_against_reference(golden, torch_dev, tag, keys):
     R, t, *_ = s.solve_pnp_LM_single_pattern(img_dict(g["uv"][i].astype(np.float64), names),
                                              s.np_point_3d_pretransfer_dict_list[0])
     assert rot_angle(R, g["R"][i])[0] <= ANG_TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# the float64 flavour of the entry points: the reference's own dtype end to end
+# ---------------------------------------------------------------------------------------------
+
+DR_F64 = 1e-9        # per rotation entry, vs the reference on identical float64 inputs
+RELT_F64 = 1e-9
+
+
+def solve_dev64(uv, xyz, dev, **kw):
+    import torch
+    pats = kw.pop("patterns", None)
+
+    def put(a):
+        return None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+
+    out = pnp.solve_pnp_batch(put(uv), put(xyz), K, patterns=put(pats), **kw)
+    torch.cuda.synchronize()
+    return to_np(out)
+
+
+def test_f64_qeif_matches_reference_to_roundoff(golden, torch_dev):
+    """Same float64 pixels and the same float64 pattern as the reference run: what is left is
+    the different order of the float64 operations."""
+    g, uv = stress_uv6(golden)
+    out = solve_dev64(uv, P6, torch_dev)
+    assert out["R"].dtype == np.float64 and out["rpy_deg"].dtype == np.float64
+    assert np.array_equal(out["iters"], g["iters"])
+    assert np.abs(out["R"] - g["R"]).max() <= DR_F64
+    assert rel_t(out["t"], g["t"]).max() <= RELT_F64
+    assert np.abs(out["res_norm"] - g["res_norm"]).max() <= 1e-9
+    rpy_ref = np.stack([g["roll"], g["yaw"], g["pitch"]], axis=1)
+    assert np.abs(out["rpy_deg"] - rpy_ref).max() <= 1e-7
+    # the float32 flavour computes the same thing on rounded inputs and rounds the result once
+    f32 = solve_dev(uv, P6f, torch_dev)
+    assert np.array_equal(f32["iters"], out["iters"])
+    assert np.abs(f32["R"] - out["R"]).max() <= 1e-5
+    # N = 68, several lanes per problem
+    g68 = golden("qeif_n68")
+    o68 = solve_dev64(g68["uv"], g68["xyz"], torch_dev)
+    assert np.array_equal(o68["iters"], g68["iters"])
+    assert np.abs(o68["R"] - g68["R"]).max() <= DR_F64 and rel_t(o68["t"], g68["t"]).max() <= RELT_F64
+    # exact (unquantised) pixels converge to the rounding floor, where the 1 % stopping rule
+    # sees round-off; compare where both ran the same number of iterations
+    e = golden("qeif_n6_exact")
+    oe = solve_dev64(e["uv"], P6, torch_dev)
+    same = oe["iters"] == e["iters"]
+    assert same.mean() >= 0.97
+    assert np.abs(oe["R"] - e["R"])[same].max() <= 1e-8
+    # pattern loop
+    m = golden("multi_pattern")
+    om = solve_dev64(m["uv"], None, torch_dev, patterns=m["xyz"])
+    assert np.array_equal(om["pattern_id"], m["pattern_id"])
+    assert np.abs(om["R"] - m["R"]).max() <= DR_F64
+    host = pnp.solve_pnp_batch(m["uv"].astype(np.float64), None, K, patterns=m["xyz"])
+    assert host["R"].dtype == np.float64 and np.array_equal(host["R"], om["R"])
+    assert np.array_equal(host["pattern_id"], om["pattern_id"])
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 8, 64])
+def test_f64_every_lane_mapping(golden, torch_dev, lanes):
+    g, uv = stress_uv6(golden)
+    lib = _lib.load()
+    lib.pnp_set_lanes_per_problem(lanes)
+    try:
+        out = solve_dev64(uv[:1500], np.broadcast_to(P6, (1500, 6, 3)), torch_dev)
+        d = solve_dev64(uv[:1500], P6, torch_dev, method="dlt")
+    finally:
+        lib.pnp_set_lanes_per_problem(0)
+    assert np.array_equal(out["iters"], g["iters"][:1500])
+    assert np.abs(out["R"] - g["R"][:1500]).max() <= DR_F64
+    ref = c_oracle.dlt_batch(uv[:1500].astype(np.float64), P6, K)
+    clear = np.isfinite(ref["R"]).all(axis=(1, 2)) & (ref["margins"][:, :2].min(axis=1) > 1e-7)
+    assert clear.mean() > 0.9
+    assert np.abs(d["R"] - ref["R"])[clear].max() <= 1e-7      # 4x4 normal equations vs the oracle's
+
+
+@pytest.mark.parametrize("tag,P", [("dlt_n6", P6), ("dlt_n15", P15)])
+def test_f64_dlt_against_reference(golden, torch_dev, tag, P):
+    g = golden(tag)
+    out = solve_dev64(g["uv"], P, torch_dev, method="dlt")
+    ref = c_oracle.dlt_batch(g["uv"].astype(np.float64), P, K)
+    ok = ~g["raised"] & np.isfinite(g["R"]).all(axis=(1, 2))
+    clear = ok & (ref["margins"][:, 0] > 1e-7) & (ref["margins"][:, 1] > 1e-7)
+    assert clear.sum() >= 0.99 * ok.sum()
+    # the reference solves the 2N x 8 system by SVD pseudo-inverse, the kernel by 4x4 normal
+    # equations: condition-number-squared round-off, still far below the float32 flavour's bound
+    assert rot_angle(out["R"], g["R"])[clear].max() <= 1e-7
+    assert rel_t(out["t"], g["t"])[clear].max() <= 1e-7
+    assert np.abs(out["res_norm"] - g["res_norm"])[clear].max() <= 1e-8
+    host = pnp.solve_pnp_batch(g["uv"].astype(np.float64), P, K, method="dlt")
+    assert np.array_equal(host["R"], out["R"], equal_nan=True)
+
+
+def test_f64_lm12_against_reference(golden, torch_dev):
+    g = golden("lm12_n6")
+    out = solve_dev64(g["uv"], P6, torch_dev, method="lm12")
+    conv = np.isfinite(g["R"]).all(axis=(1, 2)) & (g["res_norm"] < 1e-2)
+    ang = rot_angle(out["R"], g["R"])
+    ok = conv & (ang <= 1e-7)
+    assert ok.sum() >= 0.97 * conv.sum()
+    assert np.abs(out["res_norm"] - g["res_norm"])[ok].max() <= 1e-7
+
+
+def test_f64_euler_projection_and_dropin(golden, torch_dev):
+    g = golden("stress_qeif_n6")
+    rpy = pnp.euler_deg_batch(g["R"])                               # float64 in, float64 out
+    assert rpy.dtype == np.float64
+    assert np.abs(rpy - np.stack([g["roll"], g["yaw"], g["pitch"]], 1)).max() <= 1e-9
+    import torch
+    rpy_d = pnp.euler_deg_batch(torch.from_numpy(g["R"]).to(torch_dev))
+    assert rpy_d.dtype == torch.float64 and np.array_equal(rpy_d.cpu().numpy(), rpy)
+    # unquantised float64 pixels of the generator against the oracle's projection
+    roll, yaw, pitch, t = g["roll_gt"][:500], g["yaw_gt"][:500], g["pitch_gt"][:500], g["t_gt"][:500]
+    uv = pnp.project_batch(roll, yaw, pitch, t, P15, K, quantize_q=0.0, dtype=np.float64)
+    assert uv.dtype == np.float64
+    for i in range(0, 500, 25):
+        R = po.euler_to_R(roll[i], yaw[i], pitch[i], is_degree=True)
+        want = po.project(P15, K, R, t[i])[:, :2]
+        assert np.abs(uv[i] - want).max() <= 1e-9
+    q = pnp.project_batch(roll, yaw, pitch, t, P15, K, quantize_q=1.0, dtype=np.float64)
+    assert np.array_equal(q, g["uv15"][:500].astype(np.float64))
+    # the dict-based call of the drop-in now agrees with the reference to float64 round-off
+    keys15 = [str(k) for k in g["keys15"]]
+    s = pnp.PNP_SOLVER(K, [po.PATTERN_ALEXANDER], pattern_scale_list=[1.0])
+    for i in range(25):
+        R, tt, t3, r_, y_, p_, res = s.solve_pnp(img_dict(g["uv15"][i].astype(np.float64), keys15))
+        assert np.abs(R - g["R"][i]).max() <= DR_F64 and np.abs(tt[:, 0] - g["t"][i]).max() <= 1e-9
+        assert abs(r_ - g["roll"][i]) <= 1e-7 and abs(y_ - g["yaw"][i]) <= 1e-7 and abs(p_ - g["pitch"][i]) <= 1e-7
+        assert abs(res - g["res_norm"][i]) <= 1e-9
+
+
+def test_f64_dtype_rules(torch_dev):
+    import torch
+    uv32 = torch.zeros((4, 6, 2), dtype=torch.float32, device=torch_dev)
+    xyz64 = torch.zeros((6, 3), dtype=torch.float64, device=torch_dev)
+    with pytest.raises(TypeError):
+        pnp.solve_pnp_batch(uv32, xyz64, K)
+    with pytest.raises(TypeError):
+        pnp.solve_pnp_batch(np.zeros((4, 6, 2)), P6, K, dtype=np.float16)
+    out = pnp.solve_pnp_batch(np.ones((4, 6, 2), np.float32), P6, K, dtype="float64")
+    assert out["R"].dtype == np.float64
+    out = pnp.solve_pnp_batch(np.ones((4, 6, 2)), P6, K, dtype=np.float32)
+    assert out["R"].dtype == np.float32

@@ -140,10 +140,11 @@ def test_dict_to_array_glue(golden):
     keys15 = [str(k) for k in g["keys15"]]
     img = {k: np.array([[g["uv15"][i, 0]], [g["uv15"][i, 1]], [1.0]]) for i, k in enumerate(keys15)}
     uv = s._image_array(img, pnp.LM_KEY_LIST)
-    assert uv.dtype == np.float32 and uv.shape == (1, 6, 2)
+    assert uv.dtype == np.float64 and uv.shape == (1, 6, 2)      # the reference's dtype, unrounded
     assert np.array_equal(uv[0], g["uv15"][lm6_indices(g)])
     P = s._pattern_array(s.np_point_3d_pretransfer_dict_list[0], pnp.LM_KEY_LIST)
-    assert np.array_equal(P, po.pattern_array(po.PATTERN_ALEXANDER, po.LM6_KEYS).astype(np.float32))
+    assert P.dtype == np.float64
+    assert np.array_equal(P, po.pattern_array(po.PATTERN_ALEXANDER, po.LM6_KEYS))
 
 
 def test_dropin_module_is_importable_by_its_reference_name():
@@ -201,3 +202,17 @@ def test_stress_classes_and_statistics_match_reference_toolbox(golden):
     assert np.array_equal(roll, g["roll_gt"]) and np.array_equal(t, g["t_gt"])
     uv, _ = synth.stress_batch(10000, 42, pattern=po.pattern_array(po.PATTERN_ALEXANDER))
     assert np.array_equal(uv, g["uv15"])
+
+
+def test_golden_pattern_tables_match_the_reference(golden):
+    from pnp_solver_test_amd import synth
+    g = golden("known_cases")
+    assert list(synth.get_golden_pattern("Alexander")) == [str(k) for k in g["keys15"]]
+    assert synth.get_golden_pattern("Alexander") == po.PATTERN_ALEXANDER
+    assert synth.get_golden_pattern("Holly") == po.PATTERN_HOLLY
+    assert synth.get_golden_pattern("anything else") == po.PATTERN_ALEXANDER
+    assert tuple(synth.LM6_KEYS) == tuple(po.LM6_KEYS) == tuple(str(k) for k in g["lm6"])
+    m = golden("multi_pattern")            # the rows the reference's two-pattern run used
+    assert np.array_equal(synth.pattern_rows("Alexander", synth.LM6_KEYS), m["xyz"][0])
+    assert np.array_equal(synth.pattern_rows("Holly", synth.LM6_KEYS), m["xyz"][1])
+    assert np.array_equal(synth.PATTERN6, m["xyz"][0])
