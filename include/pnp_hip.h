@@ -155,6 +155,39 @@ int pnp_project_batch_f64(const double *rpy_deg, const double *t, const double *
                           double quantize_q, void *uv_out, int32_t uv_is_f64, int32_t ptr_kind,
                           void *hip_stream);
 
+/* Comparison epilogue of the reference's stress driver for B solved samples
+ * (scripts/random_stress_test.py:362-396): replaces check_if_the_sample_passed
+ * (scripts/TEST_TOOLBOX.py:55-62) and the landmark error sets of
+ * compare_result_and_generate_result_dict / cal_LM_error_distances (TEST_TOOLBOX.py:252-286,
+ * :312-343, :453-463), with get_Euler_from_rotation_matrix of the estimate fused in.
+ *   R_est (B,9), t_est (B,3)   the solver's outputs (float32 or float64 flavour)
+ *   uv_obs (B,M,2)             the pixels that were solved, for all M pattern points; NULL = the
+ *                              ground-truth projections stand in (TEST_TOOLBOX.py:317-319)
+ *   rpy_gt_deg (B,3) float64   ground-truth roll, yaw, pitch in degrees
+ *   distance_gt_cm (B) float64 ground-truth depth in cm (data_id_dict['distance'], :281)
+ *   xyz (M,3) float64          the golden pattern, shared by all samples
+ *   bound[4] (host)            pass bounds for depth[cm], roll, pitch, yaw; NULL = 10, 10, 10, 10
+ *   normalize                  != 0 scales the landmark errors by the true depth in metres
+ *                              (the *_normalize fields), 0 leaves them in pixels
+ * Outputs, each optional but at least one:
+ *   drpy_err (B,4)   estimate - truth for depth[cm], roll, pitch, yaw
+ *   pass_mask (B)    bit k set when |drpy_err[k]| < bound[k]
+ *   lm_err (B,6)     average and maximum landmark distance for observed-vs-truth,
+ *                    reprojection-vs-observed, reprojection-vs-truth, in that order
+ *   lm_key (B,3)     index of the pattern point with the (first) maximum, -1 if all are 0
+ * The ground-truth translation is the ESTIMATED direction scaled to the true depth, as the
+ * driver does (:367-368). */
+int pnp_compare_batch_f32(const float *R_est, const float *t_est, const float *uv_obs,
+                          const double *rpy_gt_deg, const double *distance_gt_cm, const double *xyz,
+                          const double K[9], int64_t B, int32_t M, const double bound[4],
+                          int32_t normalize, float *drpy_err, int32_t *pass_mask, float *lm_err,
+                          int32_t *lm_key, int32_t ptr_kind, void *hip_stream);
+int pnp_compare_batch_f64(const double *R_est, const double *t_est, const double *uv_obs,
+                          const double *rpy_gt_deg, const double *distance_gt_cm, const double *xyz,
+                          const double K[9], int64_t B, int32_t M, const double bound[4],
+                          int32_t normalize, double *drpy_err, int32_t *pass_mask, double *lm_err,
+                          int32_t *lm_key, int32_t ptr_kind, void *hip_stream);
+
 /* How many lanes of a wavefront cooperate on one problem: 1, 2, 4, 8, 16, 32 or 64
  * (64 = one wavefront per problem); 0 restores the automatic choice from (B, N).
  * Process-wide; meant for tuning and tests.  No reference counterpart. */

@@ -95,7 +95,7 @@ def main():
     ap.add_argument('--ref', default='/root/reference/scripts')
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
     ap.add_argument('--n-stress', type=int, default=10000)
-    ap.add_argument('--only', default='', help='comma-separated section numbers (1-9); default all')
+    ap.add_argument('--only', default='', help='comma-separated section numbers (1-10); default all')
     args = ap.parse_args()
     out_dir = os.path.abspath(args.out)
     os.makedirs(out_dir, exist_ok=True)
@@ -347,6 +347,52 @@ def main():
         with open(path, 'w') as f:
             json.dump(doc, f)
         print('wrote stress_stats.json (%.1f KB)' % (os.path.getsize(path) / 1024.0))
+
+    # ---- 10. comparison epilogue of the stress driver, by the reference's toolbox -----------
+    if want(10):
+        import contextlib
+        import io
+        g = np.load(os.path.join(out_dir, 'stress_qeif_n6.npz'))
+        n = len(g['t3'])
+        names = ('LM_GT', 'predict_LM', 'predict_GT')
+        avg = np.zeros((n, 3))
+        mx = np.zeros((n, 3))
+        key = np.zeros((n, 3), dtype=np.int32)
+        t_gt_est = np.zeros((n, 3))
+        failed = fit_failed = 0
+        sink = io.StringIO()
+        for i in range(n):
+            roll_gt, pitch_gt, yaw_gt = g['roll_gt'][i], g['pitch_gt'][i], g['yaw_gt'][i]
+            dist_cm = g['t_gt'][i, 2] * 100.0                         # random_stress_test.py:281
+            img = uv_to_dict(g['uv15'][i].astype(np.float64), keys15)
+            R_est, t_est = g['R'][i], g['t'][i].reshape(3, 1)
+            with contextlib.redirect_stdout(sink):
+                R_gt = est.get_rotation_matrix_from_Euler(roll_gt, yaw_gt, pitch_gt, is_degree=True)   # :365
+                tg = (t_est / g['t3'][i]) * (dist_cm * 0.01)                                           # :367-368
+                flags, pass_count = TTBX.check_if_the_sample_passed(
+                    (g['t3'][i] * 100.0, g['roll'][i], g['pitch'][i], g['yaw'][i]),
+                    (dist_cm, roll_gt, pitch_gt, yaw_gt), (10.0, 10.0, 10.0, 10.0))
+                rd, _, _ = TTBX.compare_result_and_generate_result_dict(                               # :387-396
+                    est, dict(idx=i, file_name='x', distance=dist_cm, roll=roll_gt, pitch=pitch_gt, yaw=yaw_gt,
+                              **{'class': None}),
+                    R_est, t_est, (g['roll'][i], g['pitch'][i], g['yaw'][i]), R_gt, tg,
+                    (roll_gt, pitch_gt, yaw_gt), g['res_norm'][i], 4 - pass_count, pass_count, flags,
+                    np_point_image_dict=img, verbose=False)
+            sink.seek(0)
+            sink.truncate(0)
+            for j, nm in enumerate(names):
+                avg[i, j] = rd[nm + '_error_average_normalize']
+                mx[i, j] = rd[nm + '_error_max_normalize']
+                k = rd[nm + '_error_max_key']
+                key[i, j] = keys15.index(k) if k else -1
+            t_gt_est[i] = tg[:, 0]
+            if pass_count < 4:                                        # :412-415, pass_count_threshold = 4 (:71)
+                failed += 1
+                if rd['predict_LM_error_average_normalize'] > 1.0:
+                    fit_failed += 1
+        save('stress_epilogue.npz', avg_normalized=avg, max_normalized=mx, max_key=key, t_gt_est=t_gt_est,
+             failed_sample_count=np.int64(failed), failed_sample_fit_error_count=np.int64(fit_failed),
+             names=np.array(names))
 
     print('done in %.0f s; numpy %s' % (time.time() - t_start, np.__version__))
 

@@ -425,3 +425,51 @@ def sample_random_stress_poses(rng, count):
         fov_y = rng.uniform(-45.0, 45.0, None)
         t[i] = [depth * np.tan(np.deg2rad(fov_x)), depth * np.tan(np.deg2rad(fov_y)), depth]
     return roll, pitch, yaw, t
+
+
+# ---------------------------------------------------------------------------------------------
+# comparison epilogue of the drivers (TEST_TOOLBOX.py:55-62, :252-286, :291-465)
+# ---------------------------------------------------------------------------------------------
+
+def lm_error_distances(A, B):
+    """cal_LM_error_distances (TEST_TOOLBOX.py:252-286) on two (M,3) arrays of homogeneous
+    pixels in the same landmark order: (average, max, index of the first strict maximum or -1
+    if every distance is 0)."""
+    total, mx, key = 0.0, 0.0, -1
+    for i in range(A.shape[0]):
+        e = np.linalg.norm(A[i] - B[i])
+        total += e
+        if e > mx:
+            mx, key = e, i
+    return total / A.shape[0], mx, key
+
+
+def compare_epilogue(R_est, t_est, rpy_est, rpy_gt, distance_cm, uv_obs, P, K=K_DEFAULT,
+                     bound=(10.0, 10.0, 10.0, 10.0)):
+    """What the stress driver does with one solved sample (random_stress_test.py:362-396):
+    ground-truth rotation from the ground-truth angles (:365), ground-truth translation along
+    the ESTIMATED direction scaled to the true depth (:367-368), the pass flags
+    (TEST_TOOLBOX.py:55-62; order depth, roll, pitch, yaw) and the three landmark error sets of
+    compare_result_and_generate_result_dict (TEST_TOOLBOX.py:312-343, :453-463), each normalised
+    by the true depth in metres.  rpy_* are (roll, yaw, pitch) in degrees; uv_obs (M,2) are the
+    pixels handed to the solver (None: the ground-truth projections stand in, :317-319).
+    Returns dict(drpy_err (4,), passed (4,) bool, avg (3,), max (3,), key (3,), t_gt_est (3,))
+    with the error sets ordered LM-vs-GT, reprojection-vs-LM, reprojection-vs-GT."""
+    t_est = np.asarray(t_est, dtype=np.float64).reshape(3)
+    R_gt = euler_to_R(rpy_gt[0], rpy_gt[1], rpy_gt[2], is_degree=True)
+    distance_m = distance_cm * 0.01
+    t_gt_est = (t_est / t_est[2]) * distance_m
+
+    def homog(R, t):
+        ray = (K @ (R @ P.T + t.reshape(3, 1))).T
+        return ray / np.abs(ray[:, 2:3])
+
+    reproj, gt = homog(np.asarray(R_est, dtype=np.float64), t_est), homog(R_gt, t_gt_est)
+    obs = gt if uv_obs is None else np.concatenate([np.asarray(uv_obs, dtype=np.float64),
+                                                    np.ones((P.shape[0], 1))], axis=1)
+    sets = [lm_error_distances(obs, gt), lm_error_distances(reproj, obs), lm_error_distances(reproj, gt)]
+    est = np.array([t_est[2] * 100.0, rpy_est[0], rpy_est[2], rpy_est[1]])
+    ref = np.array([distance_cm, rpy_gt[0], rpy_gt[2], rpy_gt[1]])
+    return dict(drpy_err=est - ref, passed=np.abs(est - ref) < np.asarray(bound),
+                avg=np.array([s[0] for s in sets]) * distance_m, max=np.array([s[1] for s in sets]) * distance_m,
+                key=np.array([s[2] for s in sets], dtype=np.int32), t_gt_est=t_gt_est)

@@ -31,7 +31,7 @@ EXPORTS = (
     "pnp_qeif_default_params", "pnp_device_count", "pnp_init", "pnp_qeif_batch_f32",
     "pnp_dlt_batch_f32", "pnp_lm12_batch_f32", "pnp_euler_deg_f32", "pnp_qeif_multi_batch_f32",
     "pnp_qeif_batch_f64", "pnp_dlt_batch_f64", "pnp_lm12_batch_f64", "pnp_euler_deg_f64",
-    "pnp_qeif_multi_batch_f64", "pnp_project_batch_f64",
+    "pnp_qeif_multi_batch_f64", "pnp_project_batch_f64", "pnp_compare_batch_f32", "pnp_compare_batch_f64",
     "pnp_set_lanes_per_problem", "pnp_get_lanes_per_problem", "pnp_max_points",
     "pnp_last_error", "pnp_version",
 )
@@ -80,7 +80,8 @@ def load():
                 ("pnp_dlt_batch_", [vp, vp, i64, dp, i64, i32, i32, vp, vp, vp, vp, i32, vp]),
                 ("pnp_lm12_batch_", [vp, vp, i64, dp, i64, i32, ctypes.c_double, i32, vp, vp, vp, vp, i32, vp]),
                 ("pnp_euler_deg_", [vp, i64, vp, i32, vp]),
-                ("pnp_qeif_multi_batch_", [vp, vp, i32, dp, i64, i32, pp, vp, vp, vp, vp, vp, vp, i32, vp])):
+                ("pnp_qeif_multi_batch_", [vp, vp, i32, dp, i64, i32, pp, vp, vp, vp, vp, vp, vp, i32, vp]),
+                ("pnp_compare_batch_", [vp, vp, vp, vp, vp, vp, dp, i64, i32, dp, i32, vp, vp, vp, vp, i32, vp])):
             fn = getattr(lib, name + sfx)
             fn.argtypes = args
             fn.restype = ctypes.c_int

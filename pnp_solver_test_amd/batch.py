@@ -287,3 +287,68 @@ def project_batch(roll, yaw, pitch, t, xyz, K, quantize_q=0.0, device=None, dtyp
                                              torch.cuda.current_stream(dev).cuda_stream))
         torch.cuda.current_stream(dev).synchronize()   # the float64 inputs above are temporaries
     return uv
+
+
+def compare_batch(R, t, rpy_gt_deg, distance_gt_cm, xyz, K, uv_obs=None, bound=(10.0, 10.0, 10.0, 10.0),
+                  normalize=True):
+    """Comparison epilogue of the reference's stress driver on B solved samples, on the device:
+    pass flags (TEST_TOOLBOX.check_if_the_sample_passed, :55-62) and the landmark error sets of
+    compare_result_and_generate_result_dict (:312-343, :453-463), with the Euler angles of the
+    estimate computed in the same kernel.
+
+    R (B,3,3), t (B,3)   solver outputs, float32 or float64, NumPy or torch on a HIP device
+    rpy_gt_deg (B,3)     ground-truth roll, yaw, pitch in degrees;  distance_gt_cm (B,) depth in cm
+    xyz (M,3)            the golden pattern;  uv_obs (B,M,2) the solved pixels of all M points, same
+                         kind and dtype as R (None: the ground-truth projections stand in)
+    Returns a dict of the same kind as R: drpy_err (B,4) = estimate - truth for depth[cm], roll,
+    pitch, yaw; passed (B,4) bool; lm_err_avg / lm_err_max (B,3) for observed-vs-truth,
+    reprojection-vs-observed, reprojection-vs-truth (scaled by the true depth in metres if
+    `normalize`); lm_err_key (B,3) index of the worst landmark (-1 if all distances are 0)."""
+    lib = _lib.load()
+    ft = _np_dtype(R, None)
+    fn = lib.pnp_compare_batch_f64 if ft == np.dtype(np.float64) else lib.pnp_compare_batch_f32
+    Kc = _lib.k_array(K)
+    bd = (ctypes.c_double * 4)(*[float(v) for v in bound])
+    rpy = np.ascontiguousarray(rpy_gt_deg, dtype=np.float64)
+    dist = np.ascontiguousarray(distance_gt_cm, dtype=np.float64)
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    B, M = int(dist.shape[0]), int(xyz.shape[0])
+    if rpy.shape != (B, 3) or xyz.shape != (M, 3):
+        raise ValueError("rpy_gt_deg must be (B, 3) and xyz (M, 3)")
+    bits = np.arange(4, dtype=np.int32)
+    if _is_torch(R):
+        import torch
+        dev = R.device
+        if not R.is_cuda or t.dtype != R.dtype or (uv_obs is not None and uv_obs.dtype != R.dtype):
+            raise TypeError("R, t and uv_obs must be tensors of one dtype on a HIP device")
+        if R.numel() != B * 9 or t.numel() != B * 3 or (uv_obs is not None and uv_obs.numel() != B * M * 2):
+            raise ValueError("R, t, uv_obs do not match B = %d, M = %d" % (B, M))
+        R, t = R.contiguous(), t.contiguous()
+        uv_obs = None if uv_obs is None else uv_obs.contiguous()
+        with torch.cuda.device(dev):
+            d_rpy, d_dist, d_xyz = (torch.from_numpy(a).to(dev) for a in (rpy, dist, xyz))
+            err = torch.empty((B, 4), dtype=R.dtype, device=dev)
+            lm = torch.empty((B, 6), dtype=R.dtype, device=dev)
+            mask = torch.empty(B, dtype=torch.int32, device=dev)
+            key = torch.empty((B, 3), dtype=torch.int32, device=dev)
+            stream = torch.cuda.current_stream(dev)
+            _lib.check(fn(R.data_ptr(), t.data_ptr(), None if uv_obs is None else uv_obs.data_ptr(),
+                          d_rpy.data_ptr(), d_dist.data_ptr(), d_xyz.data_ptr(), Kc, B, M, bd, int(bool(normalize)),
+                          err.data_ptr(), mask.data_ptr(), lm.data_ptr(), key.data_ptr(), _lib.PTR_DEVICE,
+                          stream.cuda_stream))
+            stream.synchronize()                       # the float64 uploads above are temporaries
+        passed = (mask[:, None] >> torch.from_numpy(bits).to(dev)[None, :]) & 1
+        return dict(drpy_err=err, passed=passed.bool(), lm_err_avg=lm[:, 0::2], lm_err_max=lm[:, 1::2],
+                    lm_err_key=key)
+    R = np.ascontiguousarray(R, dtype=ft)
+    t = np.ascontiguousarray(t, dtype=ft)
+    uv_obs = None if uv_obs is None else np.ascontiguousarray(uv_obs, dtype=ft)
+    if R.size != B * 9 or t.size != B * 3 or (uv_obs is not None and uv_obs.size != B * M * 2):
+        raise ValueError("R, t, uv_obs do not match B = %d, M = %d" % (B, M))
+    err, lm = np.empty((B, 4), ft), np.empty((B, 6), ft)
+    mask, key = np.empty(B, np.int32), np.empty((B, 3), np.int32)
+    _lib.check(fn(R.ctypes.data, t.ctypes.data, None if uv_obs is None else uv_obs.ctypes.data, rpy.ctypes.data,
+                  dist.ctypes.data, xyz.ctypes.data, Kc, B, M, bd, int(bool(normalize)), err.ctypes.data,
+                  mask.ctypes.data, lm.ctypes.data, key.ctypes.data, _lib.PTR_HOST, None))
+    passed = ((mask[:, None] >> bits[None, :]) & 1).astype(bool)
+    return dict(drpy_err=err, passed=passed, lm_err_avg=lm[:, 0::2], lm_err_max=lm[:, 1::2], lm_err_key=key)

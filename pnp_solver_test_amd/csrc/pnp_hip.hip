@@ -461,6 +461,72 @@ int project_impl(const double *rpy_deg, const double *t, const double *xyz, int6
     return PNP_OK;
 }
 
+template <typename T>
+int compare_impl(const T *R_est, const T *t_est, const T *uv_obs, const double *rpy_gt_deg,
+                 const double *distance_gt_cm, const double *xyz, const double K[9], int64_t B, int32_t M,
+                 const double bound[4], int32_t normalize, T *drpy_err, int32_t *pass_mask, T *lm_err,
+                 int32_t *lm_key, int32_t ptr_kind, void *hip_stream)
+{
+    g_err[0] = 0;
+    if (B < 0) return fail(PNP_E_ARG, "B = %lld is negative", static_cast<long long>(B));
+    if (M < 1) return fail(PNP_E_ARG, "M = %d must be >= 1", M);
+    if (!K) return fail(PNP_E_ARG, "K is NULL");
+    if (ptr_kind != PNP_PTR_HOST && ptr_kind != PNP_PTR_DEVICE)
+        return fail(PNP_E_ARG, "ptr_kind = %d is neither PNP_PTR_HOST nor PNP_PTR_DEVICE", ptr_kind);
+    if (B == 0) return PNP_OK;
+    if (!R_est || !t_est || !rpy_gt_deg || !distance_gt_cm || !xyz)
+        return fail(PNP_E_ARG, "R_est, t_est, rpy_gt_deg, distance_gt_cm and xyz must not be NULL");
+    if (!drpy_err && !pass_mask && !lm_err && !lm_key) return fail(PNP_E_ARG, "no output requested");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const int64_t nblk = (B + kBlock - 1) / kBlock;
+    if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
+    const dim3 grid(static_cast<unsigned>(nblk));
+    pnp::Mat3 Km, bd;
+    for (int i = 0; i < 9; ++i) Km.m[i] = K[i];
+    for (int i = 0; i < 9; ++i) bd.m[i] = (i < 4) ? (bound ? bound[i] : 10.0) : 0.0;
+    if (ptr_kind == PNP_PTR_DEVICE) {
+        hipLaunchKernelGGL((pnp::compare_kernel<T>), grid, dim3(kBlock), 0, s, R_est, t_est, uv_obs, rpy_gt_deg,
+                           distance_gt_cm, xyz, Km, B, M, bd, normalize, drpy_err, pass_mask, lm_err, lm_key);
+        HIP_TRY(hipGetLastError());
+        return PNP_OK;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(PNP_E_HIP, "device index %d out of range", dev);
+    Staging &st = g_staging[dev];
+    std::lock_guard<std::mutex> lock(st.mu);
+    const size_t nB = static_cast<size_t>(B);
+    int rc = staging_reserve(st, 4096 + (nB * 4 + 3 * M) * sizeof(double) + nB * (12 + 2 * M + 10) * sizeof(T) +
+                                     nB * 4 * sizeof(int32_t));
+    if (rc) return rc;
+    Carver c(st.buf);
+    double *d_rpy = c.take<double>(nB * 3);
+    double *d_dist = c.take<double>(nB);
+    double *d_xyz = c.take<double>(static_cast<size_t>(3) * M);
+    T *d_R = c.take<T>(nB * 9);
+    T *d_t = c.take<T>(nB * 3);
+    T *d_uv = uv_obs ? c.take<T>(nB * 2 * M) : nullptr;
+    T *d_err = drpy_err ? c.take<T>(nB * 4) : nullptr;
+    T *d_lm = lm_err ? c.take<T>(nB * 6) : nullptr;
+    int32_t *d_mask = pass_mask ? c.take<int32_t>(nB) : nullptr;
+    int32_t *d_key = lm_key ? c.take<int32_t>(nB * 3) : nullptr;
+    HIP_TRY(hipMemcpyAsync(d_rpy, rpy_gt_deg, nB * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_dist, distance_gt_cm, nB * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_xyz, xyz, static_cast<size_t>(3) * M * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_R, R_est, nB * 9 * sizeof(T), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_t, t_est, nB * 3 * sizeof(T), hipMemcpyHostToDevice, s));
+    if (uv_obs) HIP_TRY(hipMemcpyAsync(d_uv, uv_obs, nB * 2 * M * sizeof(T), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL((pnp::compare_kernel<T>), grid, dim3(kBlock), 0, s, d_R, d_t, d_uv, d_rpy, d_dist, d_xyz, Km, B,
+                       M, bd, normalize, d_err, d_mask, d_lm, d_key);
+    HIP_TRY(hipGetLastError());
+    if (drpy_err) HIP_TRY(hipMemcpyAsync(drpy_err, d_err, nB * 4 * sizeof(T), hipMemcpyDeviceToHost, s));
+    if (lm_err) HIP_TRY(hipMemcpyAsync(lm_err, d_lm, nB * 6 * sizeof(T), hipMemcpyDeviceToHost, s));
+    if (pass_mask) HIP_TRY(hipMemcpyAsync(pass_mask, d_mask, nB * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (lm_key) HIP_TRY(hipMemcpyAsync(lm_key, d_key, nB * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return PNP_OK;
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -592,6 +658,26 @@ int pnp_project_batch_f64(const double *rpy_deg, const double *t, const double *
                                     static_cast<double *>(uv_out), ptr_kind, hip_stream);
     return project_impl<float>(rpy_deg, t, xyz, xyz_problem_stride, K, B, N, quantize_q,
                                static_cast<float *>(uv_out), ptr_kind, hip_stream);
+}
+
+// ---- comparison epilogue ------------------------------------------------------------------------------
+
+int pnp_compare_batch_f32(const float *R_est, const float *t_est, const float *uv_obs, const double *rpy_gt_deg,
+                          const double *distance_gt_cm, const double *xyz, const double K[9], int64_t B, int32_t M,
+                          const double bound[4], int32_t normalize, float *drpy_err, int32_t *pass_mask,
+                          float *lm_err, int32_t *lm_key, int32_t ptr_kind, void *hip_stream)
+{
+    return compare_impl<float>(R_est, t_est, uv_obs, rpy_gt_deg, distance_gt_cm, xyz, K, B, M, bound, normalize,
+                               drpy_err, pass_mask, lm_err, lm_key, ptr_kind, hip_stream);
+}
+
+int pnp_compare_batch_f64(const double *R_est, const double *t_est, const double *uv_obs, const double *rpy_gt_deg,
+                          const double *distance_gt_cm, const double *xyz, const double K[9], int64_t B, int32_t M,
+                          const double bound[4], int32_t normalize, double *drpy_err, int32_t *pass_mask,
+                          double *lm_err, int32_t *lm_key, int32_t ptr_kind, void *hip_stream)
+{
+    return compare_impl<double>(R_est, t_est, uv_obs, rpy_gt_deg, distance_gt_cm, xyz, K, B, M, bound, normalize,
+                                drpy_err, pass_mask, lm_err, lm_key, ptr_kind, hip_stream);
 }
 
 // ---- tuning and introspection -----------------------------------------------------------------------

@@ -1048,6 +1048,53 @@ __global__ __launch_bounds__(kLmBlock) void lm12_kernel(
     }
 }
 
+// R = E_roll E_pitch E_yaw from angles in degrees, with the yaw sign flipped first.
+__device__ __forceinline__ void rotation_from_euler_deg(double roll_deg, double yaw_deg, double pitch_deg,
+                                                        double (&R)[9])
+{
+    constexpr double kD2R = 3.14159265358979323846 / 180.0;
+    const double roll = roll_deg * kD2R, yaw = -yaw_deg * kD2R, pitch = pitch_deg * kD2R;
+    const double c1 = cos(roll), s1 = sin(roll), c2 = cos(yaw), s2 = sin(yaw), c3 = cos(pitch), s3 = sin(pitch);
+    // E_pitch E_yaw = [[c2, 0, -s2], [s3 s2, c3, s3 c2], [c3 s2, -s3, c3 c2]], then E_roll on the left
+    const double m00 = c2, m01 = 0.0, m02 = -s2;
+    const double m10 = s3 * s2, m11 = c3, m12 = s3 * c2;
+    const double m20 = c3 * s2, m21 = -s3, m22 = c3 * c2;
+    R[0] = c1 * m00 + s1 * m10; R[1] = c1 * m01 + s1 * m11; R[2] = c1 * m02 + s1 * m12;
+    R[3] = -s1 * m00 + c1 * m10; R[4] = -s1 * m01 + c1 * m11; R[5] = -s1 * m02 + c1 * m12;
+    R[6] = m20; R[7] = m21; R[8] = m22;
+}
+
+// Homogeneous pixel of one pattern point: ray = K (R p + t), divided by |ray_z|.
+__device__ __forceinline__ void homogeneous_pixel(const Mat3 &Kmat, const double (&R)[9], const double (&t)[3],
+                                                  double X, double Y, double Z, double (&px)[3])
+{
+    const double cx = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+    const double cy = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+    const double cz = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+    const double rx = Kmat.m[0] * cx + Kmat.m[1] * cy + Kmat.m[2] * cz;
+    const double ry = Kmat.m[3] * cx + Kmat.m[4] * cy + Kmat.m[5] * cz;
+    const double rz = Kmat.m[6] * cx + Kmat.m[7] * cy + Kmat.m[8] * cz;
+    const double a = fabs(rz);
+    px[0] = rx / a;
+    px[1] = ry / a;
+    px[2] = rz / a;
+}
+
+struct ErrorSet {  // running average / maximum / first strict arg-max of landmark distances
+    double total = 0.0, worst = 0.0;
+    int key = -1;
+    __device__ __forceinline__ void add(const double (&a)[3], const double (&b)[3], int i)
+    {
+        const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+        const double e = sqrt(dx * dx + dy * dy + dz * dz);
+        total += e;
+        if (e > worst) {
+            worst = e;
+            key = i;
+        }
+    }
+};
+
 // Synthetic-input generator: pose (roll, yaw, pitch in degrees; t) -> pixels of a pattern.
 // R = E_roll E_pitch E_yaw with the yaw sign flipped first; ray = K (R p + t); the ray is
 // divided by |ray_z| and, if q > 0, rounded half-to-even onto a grid of step q.
@@ -1059,16 +1106,8 @@ __global__ __launch_bounds__(kBlock) void project_kernel(
 {
     const int64_t b = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (b >= B) return;
-    constexpr double kD2R = 3.14159265358979323846 / 180.0;
-    const double roll = rpy_deg[3 * b] * kD2R, yaw = -rpy_deg[3 * b + 1] * kD2R, pitch = rpy_deg[3 * b + 2] * kD2R;
-    const double c1 = cos(roll), s1 = sin(roll), c2 = cos(yaw), s2 = sin(yaw), c3 = cos(pitch), s3 = sin(pitch);
-    // E_pitch E_yaw = [[c2, 0, -s2], [s3 s2, c3, s3 c2], [c3 s2, -s3, c3 c2]], then E_roll on the left
-    const double m00 = c2, m01 = 0.0, m02 = -s2;
-    const double m10 = s3 * s2, m11 = c3, m12 = s3 * c2;
-    const double m20 = c3 * s2, m21 = -s3, m22 = c3 * c2;
-    const double R[9] = {c1 * m00 + s1 * m10, c1 * m01 + s1 * m11, c1 * m02 + s1 * m12,
-                         -s1 * m00 + c1 * m10, -s1 * m01 + c1 * m11, -s1 * m02 + c1 * m12,
-                         m20, m21, m22};
+    double R[9];
+    rotation_from_euler_deg(rpy_deg[3 * b], rpy_deg[3 * b + 1], rpy_deg[3 * b + 2], R);
     const double tx = t[3 * b], ty = t[3 * b + 1], tz = t[3 * b + 2];
     const double *P = xyz + b * xyz_stride;
     for (int i = 0; i < N; ++i) {
@@ -1086,6 +1125,82 @@ __global__ __launch_bounds__(kBlock) void project_kernel(
         }
         uv_out[(b * N + i) * 2] = static_cast<T>(u);
         uv_out[(b * N + i) * 2 + 1] = static_cast<T>(v);
+    }
+}
+
+// Comparison epilogue of the stress driver, one lane per solved sample.  From the estimate
+// (R_est, t_est) and the ground truth (angles in degrees, depth in cm): the Euler angles of the
+// estimate, the four errors depth[cm], roll, pitch, yaw and their pass flags |err| < bound (bits
+// 0..3 of pass_mask), the ground-truth translation taken along the ESTIMATED direction at the
+// true depth, and average / maximum / arg-max landmark distances between the observed pixels,
+// the reprojection of the estimate and the projection of the ground truth over all M pattern
+// points: lm_err (B,6) = [obs-GT avg, max, reproj-obs avg, max, reproj-GT avg, max], scaled by
+// the true depth in metres if normalize != 0; lm_key (B,3) = point index of each maximum (-1 if
+// all distances are 0).  uv_obs == nullptr substitutes the ground-truth projections.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void compare_kernel(
+    const T *__restrict__ R_est, const T *__restrict__ t_est, const T *__restrict__ uv_obs,
+    const double *__restrict__ rpy_gt_deg, const double *__restrict__ distance_gt_cm,
+    const double *__restrict__ xyz, Mat3 Kmat, int64_t B, int M, Mat3 bound, int normalize,
+    T *__restrict__ drpy_err, int32_t *__restrict__ pass_mask, T *__restrict__ lm_err,
+    int32_t *__restrict__ lm_key)
+{
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (b >= B) return;
+    double Re[9], te[3], Rg[9], tg[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Re[k] = static_cast<double>(R_est[b * 9 + k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) te[k] = static_cast<double>(t_est[b * 3 + k]);
+    const double roll_gt = rpy_gt_deg[3 * b], yaw_gt = rpy_gt_deg[3 * b + 1], pitch_gt = rpy_gt_deg[3 * b + 2];
+    const double dist_cm = distance_gt_cm[b];
+    const double dist_m = dist_cm * 0.01;
+    rotation_from_euler_deg(roll_gt, yaw_gt, pitch_gt, Rg);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tg[k] = (te[k] / te[2]) * dist_m;
+
+    double roll, yaw, pitch;
+    euler_deg(Re, roll, yaw, pitch);
+    const double err[4] = {te[2] * 100.0 - dist_cm, roll - roll_gt, pitch - pitch_gt, yaw - yaw_gt};
+    int mask = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (fabs(err[k]) < bound.m[k]) mask |= 1 << k;
+        if (drpy_err) drpy_err[b * 4 + k] = static_cast<T>(err[k]);
+    }
+    if (pass_mask) pass_mask[b] = mask;
+    if (!lm_err && !lm_key) return;
+
+    ErrorSet obs_gt, rep_obs, rep_gt;
+    for (int i = 0; i < M; ++i) {
+        const double X = xyz[3 * i], Y = xyz[3 * i + 1], Z = xyz[3 * i + 2];
+        double pe[3], pg[3], po[3];
+        homogeneous_pixel(Kmat, Re, te, X, Y, Z, pe);
+        homogeneous_pixel(Kmat, Rg, tg, X, Y, Z, pg);
+        if (uv_obs) {
+            po[0] = static_cast<double>(uv_obs[(b * M + i) * 2]);
+            po[1] = static_cast<double>(uv_obs[(b * M + i) * 2 + 1]);
+            po[2] = 1.0;
+        } else {
+            po[0] = pg[0]; po[1] = pg[1]; po[2] = pg[2];
+        }
+        obs_gt.add(po, pg, i);
+        rep_obs.add(pe, po, i);
+        rep_gt.add(pe, pg, i);
+    }
+    const double scale = normalize ? dist_m : 1.0;
+    if (lm_err) {
+        lm_err[b * 6 + 0] = static_cast<T>(obs_gt.total / M * scale);
+        lm_err[b * 6 + 1] = static_cast<T>(obs_gt.worst * scale);
+        lm_err[b * 6 + 2] = static_cast<T>(rep_obs.total / M * scale);
+        lm_err[b * 6 + 3] = static_cast<T>(rep_obs.worst * scale);
+        lm_err[b * 6 + 4] = static_cast<T>(rep_gt.total / M * scale);
+        lm_err[b * 6 + 5] = static_cast<T>(rep_gt.worst * scale);
+    }
+    if (lm_key) {
+        lm_key[b * 3 + 0] = obs_gt.key;
+        lm_key[b * 3 + 1] = rep_obs.key;
+        lm_key[b * 3 + 2] = rep_gt.key;
     }
 }
 

@@ -1,10 +1,12 @@
 """Batched counterparts of the reference's Monte-Carlo drivers.
 
-random_stress(): scripts/random_stress_test.py:226-486 as ONE projection launch and ONE solver
-launch - pose draws in the driver's order (:245-258), projection + pixel quantisation
-(PNP_SOLVER_LIB.py:4532-4557), solve_pnp on the six-landmark subset, the 10 cm / 10 deg pass
-criteria (:374-377, TEST_TOOLBOX.py:55-62), ground-truth classes (TEST_TOOLBOX.py:133-247) and
-the per-class error statistics (TEST_TOOLBOX.py:892-937, :1173-1188).
+random_stress(): scripts/random_stress_test.py:226-486 as ONE projection launch, ONE solver
+launch and ONE comparison launch - pose draws in the driver's order (:245-258), projection +
+pixel quantisation (PNP_SOLVER_LIB.py:4532-4557), solve_pnp on the six-landmark subset, the
+10 cm / 10 deg pass criteria (:374-377, TEST_TOOLBOX.py:55-62) and the landmark error sets of
+compare_result_and_generate_result_dict (TEST_TOOLBOX.py:312-343, :453-463) with the failure
+counters built on them (:408-415), ground-truth classes (TEST_TOOLBOX.py:133-247) and the
+per-class error statistics (TEST_TOOLBOX.py:892-937, :1173-1188).
 
 landmark_noise_sweep(): scripts/LM_noise_test.py:141-175, :253-360 - yaw x noise-sigma grid of
 noisy landmark sets, all cells solved in one launch, yaw-error mean / stddev / MAE meshes.
@@ -56,8 +58,10 @@ def random_stress(count, seed=42, pattern15=None, lm_rows=None, K=synth.K_DEFAUL
     """Run `count` random-stress samples.  pattern15: (M,3) golden pattern used to generate the
     landmarks (default: the six solver landmarks only); lm_rows: rows of it the solver uses.
     Returns a dict with the ground truth, the estimates, `passed` (count,4) = depth, roll, pitch,
-    yaw within bounds, `pass_count`, and `stats` = per distance class (and "all") statistics of
-    depth (cm), roll, pitch and yaw (deg) errors."""
+    yaw within bounds, `pass_count`, the normalised landmark errors `lm_err_avg` / `lm_err_max` /
+    `lm_err_key` (count,3) for observed-vs-truth, reprojection-vs-observed, reprojection-vs-truth,
+    `failed_sample_count`, `failed_sample_fit_error_count`, and `stats` = per distance class (and
+    "all") statistics of depth (cm), roll, pitch and yaw (deg) errors."""
     if pattern15 is None:
         pattern15, lm_rows = synth.PATTERN6, list(range(6))
     pattern15 = np.asarray(pattern15, dtype=np.float64)
@@ -66,11 +70,14 @@ def random_stress(count, seed=42, pattern15=None, lm_rows=None, K=synth.K_DEFAUL
     uv_all = _batch.project_batch(roll, yaw, pitch, t, pattern15, K, 1.0 if is_quantized else 0.0, device=device)
     uv = uv_all[:, lm_rows, :].contiguous()
     out = _batch.solve_pnp_batch(uv, pattern15[lm_rows].astype(np.float32), K, method="qeif")
+    cmp_ = _batch.compare_batch(out["R"], out["t"], np.stack([roll, yaw, pitch], axis=1), t[:, 2] * 100.0,
+                                pattern15, K, uv_obs=uv_all, bound=error_bound)
     res = {k: v.detach().cpu().numpy() for k, v in out.items()}
-    est = np.stack([res["t3"].astype(np.float64) * 100.0, res["rpy_deg"][:, 0], res["rpy_deg"][:, 2],
-                    res["rpy_deg"][:, 1]], axis=1)
+    res.update({k: v.detach().cpu().numpy() for k, v in cmp_.items() if k != "passed"})
     gt = np.stack([t[:, 2] * 100.0, roll, pitch, yaw], axis=1)
-    passed = np.abs(est - gt) < np.asarray(error_bound)[None, :]
+    passed = cmp_["passed"].cpu().numpy()
+    failed = passed.sum(axis=1) < 4                                   # pass_count_threshold = 4 (:71, :412)
+    fit_failed = failed & (res["lm_err_avg"][:, 1] > 1.0)             # :408, :414
     classes = {"distance": classify(gt[:, 0], "depth"), "roll": classify(roll, "roll"),
                "pitch": classify(pitch, "pitch"), "yaw": classify(yaw, "yaw")}
     stats = {}
@@ -81,7 +88,8 @@ def random_stress(count, seed=42, pattern15=None, lm_rows=None, K=synth.K_DEFAUL
                             pitch=error_statistics(res["rpy_deg"][m, 2], pitch[m]),
                             yaw=error_statistics(res["rpy_deg"][m, 1], yaw[m]))
     return dict(roll_gt=roll, pitch_gt=pitch, yaw_gt=yaw, t_gt=t, uv=uv_all.detach().cpu().numpy(), classes=classes,
-                passed=passed, pass_count=passed.sum(axis=1), stats=stats, **res)
+                passed=passed, pass_count=passed.sum(axis=1), failed_sample_count=int(failed.sum()),
+                failed_sample_fit_error_count=int(fit_failed.sum()), stats=stats, **res)
 
 
 def landmark_noise_sweep(yaw_list, sigma_list, noise, pattern15, lm_rows, K=synth.K_DEFAULT, fixed_depth=1.0,

@@ -595,6 +595,12 @@ def test_random_stress_driver_matches_reference_run(golden, torch_dev):
     assert (r["uv"] == g["uv15"]).mean() >= 0.99999
     assert r["passed"].tolist() == g["passed"].tolist()
     assert r["pass_count"].tolist() == g["passed"].sum(axis=1).tolist()
+    e = golden("stress_epilogue")                      # the reference toolbox's comparison epilogue
+    assert r["failed_sample_count"] == int(e["failed_sample_count"])
+    assert r["failed_sample_fit_error_count"] == int(e["failed_sample_fit_error_count"])
+    same_px = (r["uv"] == g["uv15"]).all(axis=(1, 2))
+    assert np.abs(r["lm_err_avg"] - e["avg_normalized"])[same_px].max() <= 5e-4
+    assert (r["lm_err_key"] == e["max_key"])[same_px].mean() >= 0.999
     assert r["classes"]["distance"].tolist() == ref["classes"]["distance"]
     assert rot_angle(r["R"], g["R"]).max() <= ANG_TOL and rel_t(r["t"], g["t"]).max() <= RELT_TOL
     for label, per in ref["stats"].items():
@@ -805,3 +811,57 @@ def test_f64_dtype_rules(torch_dev):
     assert out["R"].dtype == np.float64
     out = pnp.solve_pnp_batch(np.ones((4, 6, 2)), P6, K, dtype=np.float32)
     assert out["R"].dtype == np.float32
+
+
+# ---------------------------------------------------------------------------------------------
+# comparison epilogue of the stress driver
+# ---------------------------------------------------------------------------------------------
+
+def test_compare_epilogue_against_reference_toolbox(golden, torch_dev):
+    """Inputs are the reference's own estimates, so only the epilogue itself is under test:
+    float64 flavour to round-off, float32 flavour to its output rounding."""
+    import torch
+    g, e = golden("stress_qeif_n6"), golden("stress_epilogue")
+    rpy_gt = np.stack([g["roll_gt"], g["yaw_gt"], g["pitch_gt"]], axis=1)
+    dist_cm = g["t_gt"][:, 2] * 100.0
+    uv = g["uv15"].astype(np.float64)
+    r = pnp.compare_batch(g["R"], g["t"], rpy_gt, dist_cm, P15, K, uv_obs=uv)          # host pointers, float64
+    assert r["lm_err_avg"].dtype == np.float64
+    assert np.abs(r["lm_err_avg"] - e["avg_normalized"]).max() <= 1e-9
+    assert np.abs(r["lm_err_max"] - e["max_normalized"]).max() <= 1e-9
+    assert np.array_equal(r["lm_err_key"], e["max_key"])
+    assert r["passed"].tolist() == g["passed"].tolist()
+    est = np.stack([g["t3"] * 100.0, g["roll"], g["pitch"], g["yaw"]], axis=1)
+    gt = np.stack([dist_cm, g["roll_gt"], g["pitch_gt"], g["yaw_gt"]], axis=1)
+    assert np.abs(r["drpy_err"] - (est - gt)).max() <= 1e-9
+    failed = r["passed"].sum(axis=1) < 4
+    assert int(failed.sum()) == int(e["failed_sample_count"])
+    assert int((failed & (r["lm_err_avg"][:, 1] > 1.0)).sum()) == int(e["failed_sample_fit_error_count"])
+    # device pointers give the same bits
+    d = pnp.compare_batch(*(torch.from_numpy(a).to(torch_dev) for a in (g["R"], g["t"])), rpy_gt, dist_cm, P15, K,
+                          uv_obs=torch.from_numpy(uv).to(torch_dev))
+    assert np.array_equal(d["lm_err_avg"].cpu().numpy(), r["lm_err_avg"])
+    assert np.array_equal(d["lm_err_key"].cpu().numpy(), r["lm_err_key"])
+    assert np.array_equal(d["passed"].cpu().numpy(), r["passed"])
+    # float32 flavour on the float32-rounded estimates
+    f = pnp.compare_batch(g["R"].astype(np.float32), g["t"].astype(np.float32), rpy_gt, dist_cm, P15, K,
+                          uv_obs=g["uv15"])
+    assert f["lm_err_avg"].dtype == np.float32
+    assert np.abs(f["lm_err_avg"] - e["avg_normalized"]).max() <= 2e-4       # pixels x metres
+    assert np.abs(f["lm_err_max"] - e["max_normalized"]).max() <= 5e-4
+    assert (f["lm_err_key"] == e["max_key"]).mean() >= 0.999                 # near-ties may swap
+    # raw pixels, and the ground-truth projections standing in for the observations
+    raw = pnp.compare_batch(g["R"], g["t"], rpy_gt, dist_cm, P15, K, uv_obs=uv, normalize=False)
+    assert np.abs(raw["lm_err_avg"] * (dist_cm * 0.01)[:, None] - e["avg_normalized"]).max() <= 1e-9
+    fake = pnp.compare_batch(g["R"], g["t"], rpy_gt, dist_cm, P15, K, uv_obs=None)
+    assert np.all(fake["lm_err_avg"][:, 0] == 0.0) and np.all(fake["lm_err_key"][:, 0] == -1)
+    assert np.array_equal(fake["lm_err_avg"][:, 1], fake["lm_err_avg"][:, 2])
+    assert np.abs(fake["lm_err_avg"][:, 2] - e["avg_normalized"][:, 2]).max() <= 1e-9
+    # oracle on a few samples, other bounds
+    tight = pnp.compare_batch(g["R"], g["t"], rpy_gt, dist_cm, P15, K, uv_obs=uv, bound=(1.0, 0.5, 0.5, 0.5))
+    for i in range(0, 10000, 501):
+        o = po.compare_epilogue(g["R"][i], g["t"][i], (g["roll"][i], g["yaw"][i], g["pitch"][i]), rpy_gt[i],
+                                dist_cm[i], uv[i], P15, bound=(1.0, 0.5, 0.5, 0.5))
+        assert o["passed"].tolist() == tight["passed"][i].tolist()
+    with pytest.raises(_lib.PnpError):
+        pnp.compare_batch(g["R"][:4], g["t"][:4], rpy_gt[:4], dist_cm[:4], np.zeros((0, 3)), K)

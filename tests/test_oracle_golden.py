@@ -157,3 +157,21 @@ def test_landmark_noise_sweep(golden):
     err = yaw_est - g["yaw_list"][:, None, None]
     assert np.abs(err.mean(axis=2) - g["mesh_mean"]).max() < 1e-8
     assert np.abs(err.std(axis=2) - g["mesh_std"]).max() < 1e-8
+
+
+def test_compare_epilogue_against_reference_toolbox(golden):
+    """The drivers' comparison epilogue against TEST_TOOLBOX.compare_result_and_generate_result_dict
+    run on the reference's own stress results."""
+    g, e = golden("stress_qeif_n6"), golden("stress_epilogue")
+    P15 = po.pattern_array(po.PATTERN_ALEXANDER)
+    failed = fit_failed = 0
+    for i in range(0, 10000, 7):
+        r = po.compare_epilogue(g["R"][i], g["t"][i], (g["roll"][i], g["yaw"][i], g["pitch"][i]),
+                                (g["roll_gt"][i], g["yaw_gt"][i], g["pitch_gt"][i]), g["t_gt"][i, 2] * 100.0,
+                                g["uv15"][i], P15)
+        assert np.abs(r["avg"] - e["avg_normalized"][i]).max() <= 1e-12
+        assert np.abs(r["max"] - e["max_normalized"][i]).max() <= 1e-12
+        assert r["key"].tolist() == e["max_key"][i].tolist()
+        assert np.abs(r["t_gt_est"] - e["t_gt_est"][i]).max() <= 1e-15
+        assert r["passed"].tolist() == g["passed"][i].tolist()
+    assert int(e["failed_sample_count"]) == int((g["passed"].sum(axis=1) < 4).sum())
