@@ -193,6 +193,22 @@ int pnp_compare_batch_f64(const double *R_est, const double *t_est, const double
  * Process-wide; meant for tuning and tests.  No reference counterpart. */
 int pnp_set_lanes_per_problem(int32_t lanes);
 
+/* Which arithmetic form the QEIF entry points run.  Both follow the same recurrence and agree
+ * to float64 round-off; they differ in cost.
+ *   PNP_QEIF_FORM_POINTS   every iteration visits every point (78 N fused operations)
+ *   PNP_QEIF_FORM_MOMENTS  50 sums over the points are formed once, an iteration then costs
+ *                          about 700 fused operations whatever N is; one lane per problem
+ *   PNP_QEIF_FORM_AUTO     moments when N >= 16, B >= 32768, one pattern and no forced lane
+ *                          count; points otherwise (the default)
+ * Process-wide; meant for tuning and tests.  No reference counterpart. */
+#define PNP_QEIF_FORM_AUTO 0
+#define PNP_QEIF_FORM_POINTS 1
+#define PNP_QEIF_FORM_MOMENTS 2
+int pnp_set_qeif_form(int32_t form);
+
+/* The form (POINTS or MOMENTS) the next single-pattern QEIF launch would use for (B, N). */
+int pnp_get_qeif_form(int64_t B, int32_t N);
+
 /* The value the next float32 launch would use for (B, N). */
 int pnp_get_lanes_per_problem(int64_t B, int32_t N, int64_t xyz_problem_stride);
 

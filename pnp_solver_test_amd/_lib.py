@@ -25,6 +25,7 @@ LIB_PATH = os.environ.get("PNP_HIP_LIB") or os.path.join(_HERE, "libpnp_hip.so")
 
 PTR_HOST = 0
 PTR_DEVICE = 1
+QEIF_FORM_AUTO, QEIF_FORM_POINTS, QEIF_FORM_MOMENTS = 0, 1, 2
 
 #: every symbol include/pnp_hip.h declares
 EXPORTS = (
@@ -32,7 +33,8 @@ EXPORTS = (
     "pnp_dlt_batch_f32", "pnp_lm12_batch_f32", "pnp_euler_deg_f32", "pnp_qeif_multi_batch_f32",
     "pnp_qeif_batch_f64", "pnp_dlt_batch_f64", "pnp_lm12_batch_f64", "pnp_euler_deg_f64",
     "pnp_qeif_multi_batch_f64", "pnp_project_batch_f64", "pnp_compare_batch_f32", "pnp_compare_batch_f64",
-    "pnp_set_lanes_per_problem", "pnp_get_lanes_per_problem", "pnp_max_points",
+    "pnp_set_lanes_per_problem", "pnp_get_lanes_per_problem", "pnp_set_qeif_form", "pnp_get_qeif_form",
+    "pnp_max_points",
     "pnp_last_error", "pnp_version",
 )
 
@@ -89,6 +91,10 @@ def load():
     lib.pnp_project_batch_f64.restype = ctypes.c_int
     lib.pnp_set_lanes_per_problem.argtypes = [i32]
     lib.pnp_set_lanes_per_problem.restype = ctypes.c_int
+    lib.pnp_set_qeif_form.argtypes = [i32]
+    lib.pnp_set_qeif_form.restype = ctypes.c_int
+    lib.pnp_get_qeif_form.argtypes = [i64, i32]
+    lib.pnp_get_qeif_form.restype = ctypes.c_int
     lib.pnp_get_lanes_per_problem.argtypes = [i64, i32, i64]
     lib.pnp_get_lanes_per_problem.restype = ctypes.c_int
     lib.pnp_max_points.argtypes = []

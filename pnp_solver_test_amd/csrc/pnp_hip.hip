@@ -12,6 +12,8 @@
 #include <mutex>
 
 #include "pnp_hip.h"
+#include <algorithm>
+
 #include "pnp_kernels.hpp"
 
 namespace {
@@ -42,6 +44,12 @@ int fail(int code, const char *fmt, ...)
     } while (0)
 
 std::atomic<int> g_forced_lpi{0};
+std::atomic<int> g_qeif_form{PNP_QEIF_FORM_AUTO};
+
+// The moment form pays once an iteration's fixed cost (~700 fused operations) is below the
+// point-by-point 78 N, and needs a lane per problem's worth of problems to fill the chip.
+constexpr int kMomentMinPoints = 16;
+constexpr int64_t kMomentMinBatch = 32768;
 
 // ---- per-device staging for host-pointer calls -------------------------------------------
 
@@ -153,12 +161,49 @@ pnp::QeifParams to_device_params(const pnp_qeif_params *p)
 
 // ---- launchers (device pointers only; T = element type of the problem arrays) ----------------
 
+// True when a QEIF launch should run in moment form.
+bool use_moment_form(int64_t B, int N, int n_patterns)
+{
+    if (n_patterns != 1) return false;
+    const int form = g_qeif_form.load();
+    if (form == PNP_QEIF_FORM_POINTS) return false;
+    if (form == PNP_QEIF_FORM_MOMENTS) return true;
+    return g_forced_lpi.load() == 0 && N >= kMomentMinPoints && B >= kMomentMinBatch;
+}
+
+template <typename T>
+int launch_qeif_moment(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, const pnp::KinvRows &ki,
+                       int64_t B, int N, const pnp::QeifParams &p, T *R, T *t, T *res, int32_t *iters, T *rpy)
+{
+    constexpr int block = pnp::kSolveBlock<T>;
+    constexpr size_t row = block + 1;
+    constexpr int c_own = pnp::kMomentChunkOwn<T>, c_shared = pnp::kMomentChunkShared<T>;
+    const int64_t nblk = (B + block - 1) / block;
+    if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
+    const dim3 grid(static_cast<unsigned>(nblk));
+    if (xyz_stride == 0) {
+        const size_t lds = (2 * c_shared * row + static_cast<size_t>(3) * N) * sizeof(T);
+        hipLaunchKernelGGL((pnp::qeif_moment_kernel<T, c_shared, true>), grid, dim3(block), lds, s, uv, xyz,
+                           xyz_stride, ki, B, N, p, R, t, res, iters, rpy);
+    } else {
+        const size_t lds = 5 * c_own * row * sizeof(T);
+        hipLaunchKernelGGL((pnp::qeif_moment_kernel<T, c_own, false>), grid, dim3(block), lds, s, uv, xyz,
+                           xyz_stride, ki, B, N, p, R, t, res, iters, rpy);
+    }
+    HIP_TRY(hipGetLastError());
+    return PNP_OK;
+}
+
 template <typename T>
 int launch_qeif(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, int n_patterns,
                 const pnp::KinvRows &ki, int64_t B, int N, const pnp::QeifParams &p, T *R, T *t, T *res,
                 int32_t *iters, T *rpy, int32_t *pid)
 {
     if (B == 0) return PNP_OK;
+    if (use_moment_form(B, N, n_patterns)) {
+        if (pid) HIP_TRY(hipMemsetAsync(pid, 0, static_cast<size_t>(B) * sizeof(int32_t), s));
+        return launch_qeif_moment<T>(s, uv, xyz, xyz_stride, ki, B, N, p, R, t, res, iters, rpy);
+    }
     const int lpi = choose_lpi(B, N, xyz_stride != 0, n_patterns, sizeof(T));
     const size_t lds = lds_bytes(lpi, N, xyz_stride != 0, n_patterns, sizeof(T));
     if (lds > 64 * 1024)
@@ -689,6 +734,20 @@ int pnp_set_lanes_per_problem(int32_t lanes)
         return fail(PNP_E_ARG, "lanes = %d is not 0 or a power of two in [1, 64]", lanes);
     g_forced_lpi.store(lanes);
     return PNP_OK;
+}
+
+int pnp_set_qeif_form(int32_t form)
+{
+    g_err[0] = 0;
+    if (form != PNP_QEIF_FORM_AUTO && form != PNP_QEIF_FORM_POINTS && form != PNP_QEIF_FORM_MOMENTS)
+        return fail(PNP_E_ARG, "form = %d is not one of PNP_QEIF_FORM_*", form);
+    g_qeif_form.store(form);
+    return PNP_OK;
+}
+
+int pnp_get_qeif_form(int64_t B, int32_t N)
+{
+    return use_moment_form(B, N, 1) ? PNP_QEIF_FORM_MOMENTS : PNP_QEIF_FORM_POINTS;
 }
 
 int pnp_get_lanes_per_problem(int64_t B, int32_t N, int64_t xyz_problem_stride)

@@ -480,6 +480,198 @@ __device__ __forceinline__ void qeif_solve(const PointFetch &pts, int N, int lan
 }
 
 // ------------------------------------------------------------------------------------------
+// QEIF in moment form, for problems with many points
+// ------------------------------------------------------------------------------------------
+//
+// H^T H, H^T r and |r|^2 of the QEIF model are polynomials in the state whose coefficients are
+// sums over the points of products of (p, b p, b^2 p, b, b^2), b = nu_x or nu_y of the point:
+//   row of H_x:  a = Q1^T p - bx Q3^T p          residual  r = bx (1 + p.phi3) - p.phi1 - d1
+// so that, with S0 = sum p p^T, S1 = sum b p p^T, S2 = sum b^2 p p^T, m0 = sum p, m1 = sum b p,
+// m2 = sum b^2 p, b1 = sum b, b2 = sum b^2 (per axis),
+//   sum a a^T = Qa^T (S0 Qa - S1 Q3) - Q3^T (S1 Qa - S2 Q3)
+//   sum a     = Qa^T m0 - Q3^T m1
+//   sum a r   = Qa^T (m1 - S0 phia + S1 phi3 - d m0) - Q3^T (m2 - S1 phia + S2 phi3 - d m1)
+//   sum r     = b1 - m0.phia + m1.phi3 - n d
+//   sum r^2   = (b2 + 2 m2.phi3 + phi3^T S2 phi3) - 2 (m1.phia + d b1 + phi3^T S1 phia + d m1.phi3)
+//               + (phia^T S0 phia + 2 d m0.phia + n d^2)
+// (Qa, phia = Q1, phi1 for the x rows and Q2, phi2 for the y rows).  The 50 sums are formed
+// once per problem; an iteration then costs about 700 fused operations whatever N is, against
+// 78 N for the point-by-point form, which pays from N of about 16 upwards.
+//
+// sum r^2 is a difference of large terms: its rounding noise is about 2e-15 (b2x + b2y).  When
+// it comes out below kMomentResidualFloor (b2x + b2y) the residual is recomputed point by point
+// from global memory, so the 1 % stopping rule always sees a residual good to 1e-6 or better.
+// On pixel-quantised or noisy input that branch is never taken.
+
+constexpr double kMomentResidualFloor = 1e-8;
+
+struct AxisMoments {
+    double S1[6], S2[6], m1[3], m2[3], b1, b2;  // S*: packed lower 3x3
+};
+
+struct Moments {
+    double S0[6], m0[3];
+    AxisMoments ax, ay;
+};
+
+__device__ __forceinline__ void moments_clear(Moments &M)
+{
+#pragma unroll
+    for (int i = 0; i < 6; ++i) M.S0[i] = M.ax.S1[i] = M.ax.S2[i] = M.ay.S1[i] = M.ay.S2[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) M.m0[i] = M.ax.m1[i] = M.ax.m2[i] = M.ay.m1[i] = M.ay.m2[i] = 0.0;
+    M.ax.b1 = M.ax.b2 = M.ay.b1 = M.ay.b2 = 0.0;
+}
+
+__device__ __forceinline__ void axis_moments_add(AxisMoments &A, const double (&pp)[6], const double (&pt)[3],
+                                                 double b)
+{
+    const double bb = b * b;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        A.S1[i] = __builtin_fma(b, pp[i], A.S1[i]);
+        A.S2[i] = __builtin_fma(bb, pp[i], A.S2[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        A.m1[i] = __builtin_fma(b, pt[i], A.m1[i]);
+        A.m2[i] = __builtin_fma(bb, pt[i], A.m2[i]);
+    }
+    A.b1 += b;
+    A.b2 += bb;
+}
+
+__device__ __forceinline__ void moments_add(Moments &M, double X, double Y, double Z, double bx, double by)
+{
+    const double pt[3] = {X, Y, Z};
+    const double pp[6] = {X * X, Y * X, Y * Y, Z * X, Z * Y, Z * Z};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) M.S0[i] += pp[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) M.m0[i] += pt[i];
+    axis_moments_add(M.ax, pp, pt, bx);
+    axis_moments_add(M.ay, pp, pt, by);
+}
+
+// y = S v for a packed symmetric 3x3
+__device__ __forceinline__ void sym3_mul(const double (&S)[6], const double (&v)[3], double (&y)[3])
+{
+    y[0] = __builtin_fma(S[0], v[0], __builtin_fma(S[1], v[1], S[3] * v[2]));
+    y[1] = __builtin_fma(S[1], v[0], __builtin_fma(S[2], v[1], S[4] * v[2]));
+    y[2] = __builtin_fma(S[3], v[0], __builtin_fma(S[4], v[1], S[5] * v[2]));
+}
+
+__device__ __forceinline__ double dot3(const double (&a)[3], const double (&b)[3])
+{
+    return __builtin_fma(a[0], b[0], __builtin_fma(a[1], b[1], a[2] * b[2]));
+}
+
+// One axis' share of H^T H (AA: packed lower 4x4, accumulated), sum a, sum a r, sum r, sum r^2.
+// Qa and Q3 are 3x4 (derivatives of phia, phi3 with respect to q).
+__device__ __forceinline__ void moment_axis_terms(const double (&S0)[6], const double (&m0)[3], double n,
+                                                  const AxisMoments &A, const double (&Qa)[3][4],
+                                                  const double (&Q3)[3][4], const double (&phia)[3],
+                                                  const double (&phi3)[3], double d, double (&AA)[10],
+                                                  double (&sa)[4], double (&ga)[4], double &gd, double &rr)
+{
+    double s0a[3], s1a[3], s13[3], s23[3], w1[3], w2[3];
+    sym3_mul(S0, phia, s0a);
+    sym3_mul(A.S1, phia, s1a);
+    sym3_mul(A.S1, phi3, s13);
+    sym3_mul(A.S2, phi3, s23);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        w1[k] = __builtin_fma(-d, m0[k], (A.m1[k] - s0a[k]) + s13[k]);
+        w2[k] = __builtin_fma(-d, A.m1[k], (A.m2[k] - s1a[k]) + s23[k]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double qa[3] = {Qa[0][j], Qa[1][j], Qa[2][j]};
+        const double q3[3] = {Q3[0][j], Q3[1][j], Q3[2][j]};
+        double u0[3], u1[3], v0[3], v1[3];
+        sym3_mul(S0, qa, u0);
+        sym3_mul(A.S1, q3, u1);
+        sym3_mul(A.S1, qa, v0);
+        sym3_mul(A.S2, q3, v1);
+        const double U[3] = {u0[0] - u1[0], u0[1] - u1[1], u0[2] - u1[2]};
+        const double V[3] = {v0[0] - v1[0], v0[1] - v1[1], v0[2] - v1[2]};
+#pragma unroll
+        for (int i = j; i < 4; ++i) {
+            const double qi[3] = {Qa[0][i], Qa[1][i], Qa[2][i]};
+            const double ri[3] = {Q3[0][i], Q3[1][i], Q3[2][i]};
+            AA[tri(i, j)] += dot3(qi, U) - dot3(ri, V);
+        }
+        sa[j] = dot3(qa, m0) - dot3(q3, A.m1);
+        ga[j] = dot3(qa, w1) - dot3(q3, w2);
+    }
+    const double m1p3 = dot3(A.m1, phi3), m0pa = dot3(m0, phia);
+    gd = __builtin_fma(-n, d, (A.b1 - m0pa) + m1p3);
+    const double t_bb = __builtin_fma(2.0, dot3(A.m2, phi3), A.b2) + dot3(phi3, s23);
+    const double t_bf = __builtin_fma(d, A.b1 + m1p3, dot3(A.m1, phia)) + dot3(phi3, s1a);
+    const double t_ff = __builtin_fma(d, __builtin_fma(n, d, 2.0 * m0pa), dot3(phia, s0a));
+    rr = __builtin_fma(-2.0, t_bf, t_bb) + t_ff;
+}
+
+// One iteration from the moments; same state and recurrence as qeif_iterate.  exact_ss()
+// returns the point-by-point sum of squared residuals at the current x.
+template <typename ExactResidual>
+__device__ __forceinline__ bool qeif_moment_iterate(QeifState &st, const Moments &M, double n,
+                                                    const QeifParams &p, const ExactResidual &exact_ss)
+{
+    double(&x)[6] = st.x;
+    double(&T)[21] = st.T;
+    ++st.k;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) T[tri(i, i)] -= p.r_quat;
+    T[tri(4, 4)] -= p.r_delta;
+    T[tri(5, 5)] -= p.r_delta;
+    sweep_neg_inverse<6>(T);  // Obar
+
+    double phi[9], gamma;
+    gamma_matrix(x, phi, gamma);
+    const double a = 2.0 * x[0], b = 2.0 * x[1], c = 2.0 * x[2], d = 2.0 * x[3];
+    const double Q1[3][4] = {{a, b, -c, -d}, {-d, c, b, -a}, {c, d, a, b}};
+    const double Q2[3][4] = {{d, c, b, a}, {a, -b, c, -d}, {-b, -a, d, c}};
+    const double Q3[3][4] = {{-c, d, -a, b}, {b, a, d, c}, {a, -b, -c, d}};
+    const double phi1[3] = {phi[0], phi[1], phi[2]};
+    const double phi2[3] = {phi[3], phi[4], phi[5]};
+    const double phi3[3] = {phi[6], phi[7], phi[8]};
+    double AA[10], sax[4], say[4], gax[4], gay[4], gdx, gdy, rrx, rry;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) AA[i] = 0.0;
+    moment_axis_terms(M.S0, M.m0, n, M.ax, Q1, Q3, phi1, phi3, x[4], AA, sax, gax, gdx, rrx);
+    moment_axis_terms(M.S0, M.m0, n, M.ay, Q2, Q3, phi2, phi3, x[5], AA, say, gay, gdy, rry);
+    double ss = rrx + rry;
+    if (!(ss >= kMomentResidualFloor * (M.ax.b2 + M.ay.b2))) ss = exact_ss(x);
+
+    // Omega = Obar + q_inv H^T H
+    const double w = p.q_inv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) T[tri(i, j)] = __builtin_fma(w, AA[tri(i, j)], T[tri(i, j)]);
+        T[tri(4, i)] = __builtin_fma(w, sax[i], T[tri(4, i)]);
+        T[tri(5, i)] = __builtin_fma(w, say[i], T[tri(5, i)]);
+    }
+    T[tri(4, 4)] = __builtin_fma(w, n, T[tri(4, 4)]);
+    T[tri(5, 5)] = __builtin_fma(w, n, T[tri(5, 5)]);
+    const double g[6] = {w * (gax[0] + gay[0]), w * (gax[1] + gay[1]), w * (gax[2] + gay[2]),
+                         w * (gax[3] + gay[3]), w * gdx, w * gdy};
+    st.res = sqrt_pos(ss);
+    sweep_neg_inverse<6>(T);  // -Sigma
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double dx = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) dx = __builtin_fma(T[i >= j ? tri(i, j) : tri(j, i)], g[j], dx);
+        x[i] -= dx;
+    }
+    const bool stop = fabs(st.res - st.res_old) < p.rel_tol * st.res_old;
+    st.res_old = st.res;
+    return stop;
+}
+
+// ------------------------------------------------------------------------------------------
 // iterated linear DLT with closed-form block reconstruction
 // ------------------------------------------------------------------------------------------
 
@@ -1007,6 +1199,135 @@ __global__ __launch_bounds__(kSolveBlock<T>, PNP_QEIF_WAVES) void qeif_kernel(
         if (rpy_out) store_rpy(s.problem, R, rpy_out);
         if (pattern_id_out) pattern_id_out[s.problem] = best;
     }
+}
+
+// Points per staging pass of qeif_moment_kernel: 64-byte runs of pixels per problem when every
+// problem brings its own pattern, 128-byte runs when the pattern is shared (more LDS is free).
+template <typename T>
+constexpr int kMomentChunkOwn = 32 / static_cast<int>(sizeof(T));
+template <typename T>
+constexpr int kMomentChunkShared = 64 / static_cast<int>(sizeof(T));
+
+// QEIF in moment form over B problems of N points, one lane per problem.  The points pass
+// through LDS in chunks of C, transposed so that a lane's reads are conflict-free: element k of
+// problem j of the chunk sits at [k * (BLOCK + 1) + j].  The global loads of chunk c + 1 are
+// issued into registers before chunk c is consumed, so their latency overlaps the arithmetic.
+// A shared pattern (SHARED, xyz_stride == 0) is staged once in full and read by broadcast.
+// Dynamic LDS: SHARED ? (2 C (BLOCK + 1) + 3 N) : 5 C (BLOCK + 1) elements.
+template <typename T, int C, bool SHARED>
+__global__ __launch_bounds__(kSolveBlock<T>, PNP_QEIF_WAVES) void qeif_moment_kernel(
+    const T *__restrict__ uv, const T *__restrict__ xyz, int64_t xyz_stride, KinvRows ki, int64_t B, int N,
+    QeifParams p, T *__restrict__ R_out, T *__restrict__ t_out, T *__restrict__ res_out,
+    int32_t *__restrict__ iters_out, T *__restrict__ rpy_out)
+{
+    constexpr int BLOCK = kSolveBlock<T>;
+    constexpr int ROW = BLOCK + 1;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    T *s_uv = reinterpret_cast<T *>(lds_raw);
+    T *s_xyz = s_uv + 2 * C * ROW;
+    const int tid = threadIdx.x;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * BLOCK;
+    const int nprob = static_cast<int>(min(static_cast<int64_t>(BLOCK), B - first));
+    if constexpr (SHARED)
+        for (int i = tid; i < 3 * N; i += BLOCK) s_xyz[i] = xyz[i];
+
+    // Element e = tid + r BLOCK of a chunk belongs to problem e / (2C) (pixels) or e / (3C)
+    // (pattern): 2C and 3C loads per thread, whatever BLOCK is.
+    T pre_uv[2 * C], pre_xyz[SHARED ? 1 : 3 * C];
+    auto prefetch = [&](int c0) {
+        const int cn = min(C, N - c0);
+#pragma unroll
+        for (int r = 0; r < 2 * C; ++r) {
+            const int e = tid + r * BLOCK, j = e / (2 * C), k = e % (2 * C);
+            pre_uv[r] = (j < nprob && k < 2 * cn) ? uv[(first + j) * 2 * N + 2 * c0 + k] : T(0);
+        }
+        if constexpr (!SHARED) {
+#pragma unroll
+            for (int r = 0; r < 3 * C; ++r) {
+                const int e = tid + r * BLOCK, j = e / (3 * C), k = e % (3 * C);
+                pre_xyz[r] = (j < nprob && k < 3 * cn) ? xyz[(first + j) * xyz_stride + 3 * c0 + k] : T(0);
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int r = 0; r < 2 * C; ++r) {
+            const int e = tid + r * BLOCK;
+            s_uv[(e % (2 * C)) * ROW + e / (2 * C)] = pre_uv[r];
+        }
+        if constexpr (!SHARED) {
+#pragma unroll
+            for (int r = 0; r < 3 * C; ++r) {
+                const int e = tid + r * BLOCK;
+                s_xyz[(e % (3 * C)) * ROW + e / (3 * C)] = pre_xyz[r];
+            }
+        }
+    };
+
+    Moments M;
+    moments_clear(M);
+    prefetch(0);
+    for (int c0 = 0; c0 < N; c0 += C) {
+        const int cn = min(C, N - c0);
+        __syncthreads();  // the previous chunk has been consumed (and the shared pattern staged)
+        commit();
+        __syncthreads();
+        if (c0 + C < N) prefetch(c0 + C);
+        if (tid < nprob) {
+            for (int i = 0; i < cn; ++i) {
+                const double u = static_cast<double>(s_uv[(2 * i) * ROW + tid]);
+                const double v = static_cast<double>(s_uv[(2 * i + 1) * ROW + tid]);
+                double X, Y, Z;
+                if constexpr (SHARED) {
+                    X = static_cast<double>(s_xyz[3 * (c0 + i)]);
+                    Y = static_cast<double>(s_xyz[3 * (c0 + i) + 1]);
+                    Z = static_cast<double>(s_xyz[3 * (c0 + i) + 2]);
+                } else {
+                    X = static_cast<double>(s_xyz[(3 * i) * ROW + tid]);
+                    Y = static_cast<double>(s_xyz[(3 * i + 1) * ROW + tid]);
+                    Z = static_cast<double>(s_xyz[(3 * i + 2) * ROW + tid]);
+                }
+                const double bx = __builtin_fma(ki.a00, u, __builtin_fma(ki.a01, v, ki.a02));
+                const double by = __builtin_fma(ki.a10, u, __builtin_fma(ki.a11, v, ki.a12));
+                moments_add(M, X, Y, Z, bx, by);
+            }
+        }
+    }
+    if (tid >= nprob) return;  // no barrier follows
+
+    const int64_t problem = first + tid;
+    const T *my_uv = uv + problem * 2 * N;
+    const T *my_xyz = xyz + problem * xyz_stride;
+    auto exact_ss = [&](const double (&x)[6]) {
+        double phi[9], gamma, ss = 0.0;
+        gamma_matrix(x, phi, gamma);
+        for (int i = 0; i < N; ++i) {
+            const double u = static_cast<double>(my_uv[2 * i]), v = static_cast<double>(my_uv[2 * i + 1]);
+            const double X = static_cast<double>(my_xyz[3 * i]), Y = static_cast<double>(my_xyz[3 * i + 1]);
+            const double Z = static_cast<double>(my_xyz[3 * i + 2]);
+            const double bx = __builtin_fma(ki.a00, u, __builtin_fma(ki.a01, v, ki.a02));
+            const double by = __builtin_fma(ki.a10, u, __builtin_fma(ki.a11, v, ki.a12));
+            const double p1 = __builtin_fma(X, phi[0], __builtin_fma(Y, phi[1], Z * phi[2]));
+            const double p2 = __builtin_fma(X, phi[3], __builtin_fma(Y, phi[4], Z * phi[5]));
+            const double p3 = __builtin_fma(X, phi[6], __builtin_fma(Y, phi[7], Z * phi[8]));
+            const double rx = (bx - x[4]) - __builtin_fma(-bx, p3, p1);
+            const double ry = (by - x[5]) - __builtin_fma(-by, p3, p2);
+            ss = __builtin_fma(rx, rx, __builtin_fma(ry, ry, ss));
+        }
+        return ss;
+    };
+    QeifState st;
+    qeif_init(st, p);
+    const double n = static_cast<double>(N);
+    while (st.k < p.max_it) {
+        if (qeif_moment_iterate(st, M, n, p, exact_ss)) break;
+    }
+    double R[9], t[3];
+    qeif_finish(st, R, t);
+    store_pose(problem, R, t, R_out, t_out);
+    if (res_out) res_out[problem] = static_cast<T>(st.res);
+    if (iters_out) iters_out[problem] = st.k;
+    if (rpy_out) store_rpy(problem, R, rpy_out);
 }
 
 template <int LPI, int NCT, typename T>

@@ -865,3 +865,85 @@ def test_compare_epilogue_against_reference_toolbox(golden, torch_dev):
         assert o["passed"].tolist() == tight["passed"][i].tolist()
     with pytest.raises(_lib.PnpError):
         pnp.compare_batch(g["R"][:4], g["t"][:4], rpy_gt[:4], dist_cm[:4], np.zeros((0, 3)), K)
+
+
+# ---------------------------------------------------------------------------------------------
+# QEIF in moment form (the large-N kernel) against the same golden vectors and the point form
+# ---------------------------------------------------------------------------------------------
+
+@pytest.fixture
+def moment_form():
+    lib = _lib.load()
+    lib.pnp_set_qeif_form(_lib.QEIF_FORM_MOMENTS)
+    yield lib
+    lib.pnp_set_qeif_form(_lib.QEIF_FORM_AUTO)
+
+
+def test_moment_form_n68_against_reference(golden, torch_dev, moment_form):
+    g = golden("qeif_n68")
+    out = solve_dev64(g["uv"], g["xyz"], torch_dev)                      # shared pattern, float64
+    assert np.array_equal(out["iters"], g["iters"])
+    assert np.abs(out["R"] - g["R"]).max() <= DR_F64 and rel_t(out["t"], g["t"]).max() <= RELT_F64
+    assert np.abs(out["res_norm"] - g["res_norm"]).max() <= 1e-9
+    own = np.broadcast_to(g["xyz"], (len(g["uv"]),) + g["xyz"].shape)
+    out2 = solve_dev64(g["uv"], own, torch_dev)                          # per-problem patterns
+    assert np.array_equal(out2["iters"], g["iters"]) and np.abs(out2["R"] - out["R"]).max() <= 1e-12
+    xyz32 = g["xyz"].astype(np.float32)
+    f32 = solve_dev(g["uv"], xyz32, torch_dev)                           # float32 flavour
+    assert rot_angle(f32["R"], g["R"]).max() <= ANG_TOL and rel_t(f32["t"], g["t"]).max() <= RELT_TOL
+    ref = c_oracle.qeif_batch(g["uv"].astype(np.float64), xyz32.astype(np.float64), K)
+    assert np.array_equal(f32["iters"], ref["iters"])
+    assert_tight(f32, ref)
+    host = pnp.solve_pnp_batch(g["uv"], xyz32, K)                        # host pointers
+    assert np.array_equal(host["R"], f32["R"]) and np.array_equal(host["rpy_deg"], f32["rpy_deg"])
+
+
+def test_moment_form_equals_point_form(golden, torch_dev):
+    """Same problems through both forms: 15 points (two staging chunks, the second partial),
+    ragged batch sizes, shared and per-problem patterns."""
+    g = golden("stress_qeif_n6")
+    lib = _lib.load()
+    uv = g["uv15"][:1500]
+    outs = {}
+    for form in (_lib.QEIF_FORM_POINTS, _lib.QEIF_FORM_MOMENTS):
+        lib.pnp_set_qeif_form(form)
+        try:
+            outs[form] = [solve_dev64(uv[:B], P15, torch_dev) for B in (1, 127, 128, 129, 1500)]
+            outs[form].append(solve_dev64(uv[:700], np.broadcast_to(P15, (700, 15, 3)), torch_dev))
+            outs[form].append(solve_dev(uv[:700], P15.astype(np.float32), torch_dev))
+        finally:
+            lib.pnp_set_qeif_form(_lib.QEIF_FORM_AUTO)
+    for a, b in zip(outs[_lib.QEIF_FORM_POINTS], outs[_lib.QEIF_FORM_MOMENTS]):
+        assert np.array_equal(a["iters"], b["iters"])
+        tol = 1e-10 if a["R"].dtype == np.float64 else 2e-7
+        assert np.abs(a["R"] - b["R"]).max() <= tol and np.abs(a["t"] - b["t"]).max() <= tol
+        assert np.abs(a["res_norm"] - b["res_norm"]).max() <= tol
+        assert np.abs(a["rpy_deg"] - b["rpy_deg"]).max() <= (1e-8 if a["R"].dtype == np.float64 else 1e-4)
+
+
+def test_moment_form_small_residuals_fall_back_to_points(golden, torch_dev, moment_form):
+    """Unquantised pixels converge to residuals of 1e-8, far below the round-off of the moment
+    expression for |r|^2: the kernel must take its point-by-point residual there, or the
+    stopping rule would see noise."""
+    e = golden("qeif_n6_exact")
+    out = solve_dev64(e["uv"], P6, torch_dev)
+    same = out["iters"] == e["iters"]
+    assert same.mean() >= 0.97
+    assert np.abs(out["R"] - e["R"])[same].max() <= 1e-8
+    assert np.abs(out["res_norm"] - e["res_norm"])[same].max() <= 1e-12
+    g, uv = stress_uv6(golden)                                           # quantised, N = 6
+    q = solve_dev64(uv, P6, torch_dev)
+    assert np.array_equal(q["iters"], g["iters"]) and np.abs(q["R"] - g["R"]).max() <= DR_F64
+
+
+def test_moment_form_selection_rules(torch_dev):
+    lib = _lib.load()
+    assert lib.pnp_get_qeif_form(1 << 18, 68) == _lib.QEIF_FORM_MOMENTS
+    assert lib.pnp_get_qeif_form(1 << 20, 6) == _lib.QEIF_FORM_POINTS
+    assert lib.pnp_get_qeif_form(1000, 68) == _lib.QEIF_FORM_POINTS
+    lib.pnp_set_lanes_per_problem(4)
+    try:
+        assert lib.pnp_get_qeif_form(1 << 18, 68) == _lib.QEIF_FORM_POINTS
+    finally:
+        lib.pnp_set_lanes_per_problem(0)
+    assert lib.pnp_set_qeif_form(7) < 0
