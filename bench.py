@@ -48,6 +48,13 @@ def qeif_flops(n_points, iters_mean):
     return 2.0 * iters_mean * (78.0 * n_points + 2 * 150.0 + 60.0)
 
 
+def qeif_moment_flops(n_points, iters_mean):
+    """float64 flops (fma = 2) per solve of the moment form: 58 fused ops per point once, then
+    per iteration ~700 for H^T H, H^T r and |r|^2 from the 50 sums, two 6x6 sweeps and ~60 for
+    the update and the stopping rule."""
+    return 2.0 * (58.0 * n_points + iters_mean * (700.0 + 2 * 150.0 + 60.0))
+
+
 def dlt_flops(n_points, num_it=3):
     return 2.0 * (num_it * (30.0 * n_points + 110.0) + 20.0 * n_points)
 
@@ -242,15 +249,26 @@ def main():
             uv68_h, _ = synth.stress_batch(B68, seed=46, pattern=P68, K=K, is_quantized=True, chunk=1 << 15)
             uv68 = torch.from_numpy(uv68_h).to(dev)
             P68d = torch.from_numpy(P68.astype(np.float32)).to(dev)
+            lib = pnp._lib.load()
             o68 = pnp.solve_pnp_batch(uv68, P68d, K, want_rpy=False)
             it68 = float(o68["iters"].float().mean().item())
-            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv68, P68d, K, want_rpy=False), n_small, 3)
-            gbs = B68 * (8 * 68 + 48) / (ms * 1e-3) / 1e9
-            other["configs[3]_qeif_n68_b256k_shared_pattern"] = dict(
-                solves_per_s=round(B68 / ms * 1e3, 1), kernel_ms=round(ms, 4), mean_iterations=round(it68, 3),
-                bytes_per_solve=8 * 68 + 48, achieved_GBps=round(gbs, 1),
-                lanes_per_problem=pnp._lib.load().pnp_get_lanes_per_problem(B68, 68, 0),
+            own68 = P68d[None].expand(B68, 68, 3).contiguous()
+            for tag, xyz68, nbytes in (("shared_pattern", P68d, 8 * 68 + 48), ("per_problem_pattern", own68, 20 * 68 + 48)):
+                ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv68, xyz68, K, want_rpy=False), n_small, 3)
+                gbs = B68 * nbytes / (ms * 1e-3) / 1e9
+                other["configs[3]_qeif_n68_b256k_" + tag] = dict(
+                    solves_per_s=round(B68 / ms * 1e3, 1), kernel_ms=round(ms, 4), mean_iterations=round(it68, 3),
+                    bytes_per_solve=nbytes, achieved_GBps=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4),
+                    form="moments" if lib.pnp_get_qeif_form(B68, 68) == pnp._lib.QEIF_FORM_MOMENTS else "points",
+                    valu_fp64_TFLOPs=round(B68 * qeif_moment_flops(68, it68) / (ms * 1e-3) / 1e12, 2))
+            lib.pnp_set_qeif_form(pnp._lib.QEIF_FORM_POINTS)        # the point-by-point form, for comparison
+            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv68, P68d, K, want_rpy=False), 5, 2)
+            lib.pnp_set_qeif_form(pnp._lib.QEIF_FORM_AUTO)
+            other["configs[3]_qeif_n68_b256k_shared_pattern_point_form"] = dict(
+                solves_per_s=round(B68 / ms * 1e3, 1), kernel_ms=round(ms, 4),
+                lanes_per_problem=lib.pnp_get_lanes_per_problem(B68, 68, 0),
                 valu_fp64_TFLOPs=round(B68 * qeif_flops(68, it68) / (ms * 1e-3) / 1e12, 2))
+            del own68
             uv64, xyz64 = uv.double(), xyz.double()          # the reference's own dtype end to end
             ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv64, xyz64, K, want_rpy=False), n_small, 3)
             other["qeif_n6_b1m_float64_io"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4),

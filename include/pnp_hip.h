@@ -198,7 +198,7 @@ int pnp_set_lanes_per_problem(int32_t lanes);
  *   PNP_QEIF_FORM_POINTS   every iteration visits every point (78 N fused operations)
  *   PNP_QEIF_FORM_MOMENTS  50 sums over the points are formed once, an iteration then costs
  *                          about 700 fused operations whatever N is; one lane per problem
- *   PNP_QEIF_FORM_AUTO     moments when N >= 16, B >= 32768, one pattern and no forced lane
+ *   PNP_QEIF_FORM_AUTO     moments when N >= 10, B >= 2048, one pattern and no forced lane
  *                          count; points otherwise (the default)
  * Process-wide; meant for tuning and tests.  No reference counterpart. */
 #define PNP_QEIF_FORM_AUTO 0

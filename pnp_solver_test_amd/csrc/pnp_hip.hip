@@ -47,9 +47,11 @@ std::atomic<int> g_forced_lpi{0};
 std::atomic<int> g_qeif_form{PNP_QEIF_FORM_AUTO};
 
 // The moment form pays once an iteration's fixed cost (~700 fused operations) is below the
-// point-by-point 78 N, and needs a lane per problem's worth of problems to fill the chip.
-constexpr int kMomentMinPoints = 16;
-constexpr int64_t kMomentMinBatch = 32768;
+// point-by-point 78 N: measured crossover between N = 8 and N = 10 at half a million problems.
+// It runs one lane per problem; at N = 68 it is the faster form down to 2048 problems (the
+// smallest batch measured), below that the many-lanes-per-problem point form is kept.
+constexpr int kMomentMinPoints = 10;
+constexpr int64_t kMomentMinBatch = 2048;
 
 // ---- per-device staging for host-pointer calls -------------------------------------------
 

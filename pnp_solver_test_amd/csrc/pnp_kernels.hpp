@@ -1231,35 +1231,41 @@ __global__ __launch_bounds__(kSolveBlock<T>, PNP_QEIF_WAVES) void qeif_moment_ke
     if constexpr (SHARED)
         for (int i = tid; i < 3 * N; i += BLOCK) s_xyz[i] = xyz[i];
 
-    // Element e = tid + r BLOCK of a chunk belongs to problem e / (2C) (pixels) or e / (3C)
-    // (pattern): 2C and 3C loads per thread, whatever BLOCK is.
-    T pre_uv[2 * C], pre_xyz[SHARED ? 1 : 3 * C];
+    // A chunk holds, per problem, a run of 2C pixel elements and a run of 3C pattern elements.
+    // LU = 2C lanes share one pixel run and LX = 4C lanes one pattern run (3C of them active), so
+    // that thread tid keeps the same element index k within the run and steps through problems
+    // j0, j0 + JU, ... (JU = BLOCK / LU): offsets advance by a uniform stride per load, the LDS
+    // destination by a compile-time constant.  Out-of-range problems and elements are clamped
+    // to valid addresses; what they load is never read.
+    constexpr int LU = 2 * C, JU = BLOCK / LU, LX = 4 * C, JX = BLOCK / LX;
+    static_assert(BLOCK % LU == 0 && BLOCK % LX == 0, "chunk runs must tile the workgroup");
+    const T *uv_blk = uv + first * 2 * N;
+    const T *xyz_blk = xyz + first * xyz_stride;
+    const int ku = tid % LU, ju = tid / LU, kx = tid % LX, jx = tid / LX;
+    const unsigned row_u = 2u * static_cast<unsigned>(N), row_x = static_cast<unsigned>(xyz_stride);
+    const int jmax = nprob - 1;
+    T pre_uv[LU], pre_xyz[SHARED ? 1 : LX];
     auto prefetch = [&](int c0) {
         const int cn = min(C, N - c0);
+        const unsigned ou = 2u * c0 + (ku < 2 * cn ? ku : 0);
 #pragma unroll
-        for (int r = 0; r < 2 * C; ++r) {
-            const int e = tid + r * BLOCK, j = e / (2 * C), k = e % (2 * C);
-            pre_uv[r] = (j < nprob && k < 2 * cn) ? uv[(first + j) * 2 * N + 2 * c0 + k] : T(0);
-        }
+        for (int r = 0; r < LU; ++r) pre_uv[r] = uv_blk[static_cast<unsigned>(min(ju + r * JU, jmax)) * row_u + ou];
         if constexpr (!SHARED) {
+            const unsigned ox = 3u * c0 + (kx < 3 * cn ? kx : 0);
 #pragma unroll
-            for (int r = 0; r < 3 * C; ++r) {
-                const int e = tid + r * BLOCK, j = e / (3 * C), k = e % (3 * C);
-                pre_xyz[r] = (j < nprob && k < 3 * cn) ? xyz[(first + j) * xyz_stride + 3 * c0 + k] : T(0);
-            }
+            for (int r = 0; r < LX; ++r)
+                pre_xyz[r] = xyz_blk[static_cast<unsigned>(min(jx + r * JX, jmax)) * row_x + ox];
         }
     };
     auto commit = [&]() {
+        T *du = s_uv + ku * ROW + ju;
 #pragma unroll
-        for (int r = 0; r < 2 * C; ++r) {
-            const int e = tid + r * BLOCK;
-            s_uv[(e % (2 * C)) * ROW + e / (2 * C)] = pre_uv[r];
-        }
+        for (int r = 0; r < LU; ++r) du[r * JU] = pre_uv[r];
         if constexpr (!SHARED) {
+            if (kx < 3 * C) {
+                T *dx = s_xyz + kx * ROW + jx;
 #pragma unroll
-            for (int r = 0; r < 3 * C; ++r) {
-                const int e = tid + r * BLOCK;
-                s_xyz[(e % (3 * C)) * ROW + e / (3 * C)] = pre_xyz[r];
+                for (int r = 0; r < LX; ++r) dx[r * JX] = pre_xyz[r];
             }
         }
     };

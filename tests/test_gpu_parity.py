@@ -940,6 +940,7 @@ def test_moment_form_selection_rules(torch_dev):
     lib = _lib.load()
     assert lib.pnp_get_qeif_form(1 << 18, 68) == _lib.QEIF_FORM_MOMENTS
     assert lib.pnp_get_qeif_form(1 << 20, 6) == _lib.QEIF_FORM_POINTS
+    assert lib.pnp_get_qeif_form(1 << 20, 10) == _lib.QEIF_FORM_MOMENTS
     assert lib.pnp_get_qeif_form(1000, 68) == _lib.QEIF_FORM_POINTS
     lib.pnp_set_lanes_per_problem(4)
     try:
