@@ -216,12 +216,19 @@ int launch_qeif(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, in
     const int64_t nblk = (B + pb - 1) / pb;
     if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
     const dim3 grid(static_cast<unsigned>(nblk));
-#define PNP_Q(LPI_, NCT_)                                                                                 \
-    hipLaunchKernelGGL((pnp::qeif_kernel<LPI_, NCT_, T>), grid, dim3(block), lds, s, uv, xyz, xyz_stride, \
-                       n_patterns, ki, B, N, p, R, t, res, iters, rpy, pid)
+#define PNP_Q(LPI_, NCT_)                                                                                    \
+    do {                                                                                                     \
+        if (n_patterns > 1)                                                                                  \
+            hipLaunchKernelGGL((pnp::qeif_kernel<LPI_, NCT_, T, true>), grid, dim3(block), lds, s, uv, xyz,  \
+                               xyz_stride, n_patterns, ki, B, N, p, R, t, res, iters, rpy, pid);             \
+        else                                                                                                 \
+            hipLaunchKernelGGL((pnp::qeif_kernel<LPI_, NCT_, T, false>), grid, dim3(block), lds, s, uv, xyz, \
+                               xyz_stride, n_patterns, ki, B, N, p, R, t, res, iters, rpy, pid);             \
+    } while (0)
     switch (lpi) {
     case 1:
-        if (N == 6) PNP_Q(1, 6); else PNP_Q(1, 0);
+        if (N == 6) PNP_Q(1, 6);
+        else PNP_Q(1, 0);
         break;
     case 2: PNP_Q(2, 0); break;
     case 4: PNP_Q(4, 0); break;

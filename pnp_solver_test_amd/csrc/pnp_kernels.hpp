@@ -1143,10 +1143,11 @@ __device__ __forceinline__ void store_rpy(int64_t problem, const double (&R)[9],
     rpy_out[problem * 3 + 2] = static_cast<T>(pitch);
 }
 
-// QEIF over B problems.  n_patterns > 1 (shared patterns only) solves every problem against
-// each pattern in turn and keeps the first one with the strictly smallest residual.
+// QEIF over B problems.  n_patterns > 1 (shared patterns only, MULTI) solves every problem
+// against each pattern in turn and keeps the first one with the strictly smallest residual;
+// the single-pattern instantiation carries no second solve and so needs fewer registers.
 // NCT > 0 requires LPI == 1 and N == NCT.
-template <int LPI, int NCT, typename T>
+template <int LPI, int NCT, typename T, bool MULTI>
 __global__ __launch_bounds__(kSolveBlock<T>, PNP_QEIF_WAVES) void qeif_kernel(
     const T *__restrict__ uv, const T *__restrict__ xyz, int64_t xyz_stride, int n_patterns, KinvRows ki,
     int64_t B, int N, QeifParams p, T *__restrict__ R_out, T *__restrict__ t_out, T *__restrict__ res_out,
@@ -1158,7 +1159,7 @@ __global__ __launch_bounds__(kSolveBlock<T>, PNP_QEIF_WAVES) void qeif_kernel(
     if constexpr (NCT > 0) {
         RegPoints<NCT> rp(s.pts);
         qeif_solve<1, NCT>(rp, N, 0, p, R, t, res, iters);
-        for (int k = 1; k < n_patterns; ++k) {
+        for (int k = 1; MULTI && k < n_patterns; ++k) {
             s.pts.xyz += s.xyz_step;
             rp.set_pattern(s.pts);
             double R2[9], t2[3], res2;
@@ -1176,7 +1177,7 @@ __global__ __launch_bounds__(kSolveBlock<T>, PNP_QEIF_WAVES) void qeif_kernel(
         }
     } else {
         qeif_solve<LPI, 0>(s.pts, N, s.lane_in_group, p, R, t, res, iters);
-        for (int k = 1; k < n_patterns; ++k) {
+        for (int k = 1; MULTI && k < n_patterns; ++k) {
             s.pts.xyz += s.xyz_step;
             double R2[9], t2[3], res2;
             int it2;
