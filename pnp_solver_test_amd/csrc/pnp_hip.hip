@@ -184,9 +184,16 @@ int launch_qeif_moment(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_str
     if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
     const dim3 grid(static_cast<unsigned>(nblk));
     if (xyz_stride == 0) {
-        const size_t lds = (2 * c_shared * row + static_cast<size_t>(3) * N) * sizeof(T);
-        hipLaunchKernelGGL((pnp::qeif_moment_kernel<T, c_shared, true>), grid, dim3(block), lds, s, uv, xyz,
-                           xyz_stride, ki, B, N, p, R, t, res, iters, rpy);
+        // pixel chunk + 72 bytes per pattern point; the long chunk only while that fits 64 KB
+        const size_t pat = static_cast<size_t>(9) * N * sizeof(double);
+        const size_t lds_long = ((2 * c_shared * row * sizeof(T) + 7) & ~static_cast<size_t>(7)) + pat;
+        const size_t lds_short = ((2 * c_own * row * sizeof(T) + 7) & ~static_cast<size_t>(7)) + pat;
+        if (lds_long <= 64 * 1024)
+            hipLaunchKernelGGL((pnp::qeif_moment_kernel<T, c_shared, true>), grid, dim3(block), lds_long, s, uv, xyz,
+                               xyz_stride, ki, B, N, p, R, t, res, iters, rpy);
+        else
+            hipLaunchKernelGGL((pnp::qeif_moment_kernel<T, c_own, true>), grid, dim3(block), lds_short, s, uv, xyz,
+                               xyz_stride, ki, B, N, p, R, t, res, iters, rpy);
     } else {
         const size_t lds = 5 * c_own * row * sizeof(T);
         hipLaunchKernelGGL((pnp::qeif_moment_kernel<T, c_own, false>), grid, dim3(block), lds, s, uv, xyz,

@@ -541,6 +541,14 @@ __device__ __forceinline__ void axis_moments_add(AxisMoments &A, const double (&
     A.b2 += bb;
 }
 
+// The pixel-dependent sums only; pp = packed lower p p^T, pt = p.
+__device__ __forceinline__ void moments_add_axes(Moments &M, const double (&pp)[6], const double (&pt)[3],
+                                                 double bx, double by)
+{
+    axis_moments_add(M.ax, pp, pt, bx);
+    axis_moments_add(M.ay, pp, pt, by);
+}
+
 __device__ __forceinline__ void moments_add(Moments &M, double X, double Y, double Z, double bx, double by)
 {
     const double pt[3] = {X, Y, Z};
@@ -1213,8 +1221,11 @@ constexpr int kMomentChunkShared = 64 / static_cast<int>(sizeof(T));
 // through LDS in chunks of C, transposed so that a lane's reads are conflict-free: element k of
 // problem j of the chunk sits at [k * (BLOCK + 1) + j].  The global loads of chunk c + 1 are
 // issued into registers before chunk c is consumed, so their latency overlaps the arithmetic.
-// A shared pattern (SHARED, xyz_stride == 0) is staged once in full and read by broadcast.
-// Dynamic LDS: SHARED ? (2 C (BLOCK + 1) + 3 N) : 5 C (BLOCK + 1) elements.
+// A shared pattern (SHARED, xyz_stride == 0) is staged once as float64 [p, packed p p^T] per
+// point (9 doubles, read by broadcast), and its own sums S0 = sum p p^T, m0 = sum p are formed
+// once per wavefront, the lanes splitting the points, instead of once per problem.
+// Dynamic LDS: SHARED ? 2 C (BLOCK + 1) elements, rounded up to 8 bytes, + 9 N doubles
+//                     : 5 C (BLOCK + 1) elements.
 template <typename T, int C, bool SHARED>
 __global__ __launch_bounds__(kSolveBlock<T>, PNP_QEIF_WAVES) void qeif_moment_kernel(
     const T *__restrict__ uv, const T *__restrict__ xyz, int64_t xyz_stride, KinvRows ki, int64_t B, int N,
@@ -1226,11 +1237,30 @@ __global__ __launch_bounds__(kSolveBlock<T>, PNP_QEIF_WAVES) void qeif_moment_ke
     extern __shared__ __align__(16) unsigned char lds_raw[];
     T *s_uv = reinterpret_cast<T *>(lds_raw);
     T *s_xyz = s_uv + 2 * C * ROW;
+    double *s_pat = reinterpret_cast<double *>(lds_raw + ((2 * C * ROW * sizeof(T) + 7) & ~static_cast<size_t>(7)));
     const int tid = threadIdx.x;
     const int64_t first = static_cast<int64_t>(blockIdx.x) * BLOCK;
     const int nprob = static_cast<int>(min(static_cast<int64_t>(BLOCK), B - first));
-    if constexpr (SHARED)
-        for (int i = tid; i < 3 * N; i += BLOCK) s_xyz[i] = xyz[i];
+    Moments M;
+    moments_clear(M);
+    if constexpr (SHARED) {
+        for (int i = tid; i < N; i += BLOCK) {
+            const double X = static_cast<double>(xyz[3 * i]), Y = static_cast<double>(xyz[3 * i + 1]);
+            const double Z = static_cast<double>(xyz[3 * i + 2]);
+            double *d = s_pat + 9 * i;
+            d[0] = X; d[1] = Y; d[2] = Z;
+            d[3] = X * X; d[4] = Y * X; d[5] = Y * Y; d[6] = Z * X; d[7] = Z * Y; d[8] = Z * Z;
+        }
+        __syncthreads();
+        double part[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int i = tid & 63; i < N; i += 64)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) part[k] += s_pat[9 * i + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) M.m0[k] = group_sum<64>(part[k]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) M.S0[k] = group_sum<64>(part[3 + k]);
+    }
 
     // A chunk holds, per problem, a run of 2C pixel elements and a run of 3C pattern elements.
     // LU = 2C lanes share one pixel run and LX = 4C lanes one pattern run (3C of them active), so
@@ -1271,32 +1301,48 @@ __global__ __launch_bounds__(kSolveBlock<T>, PNP_QEIF_WAVES) void qeif_moment_ke
         }
     };
 
-    Moments M;
-    moments_clear(M);
+    // One staged point as the accumulation needs it.  The loop below fetches point i + 1 from
+    // LDS before it accumulates point i, so that the read latency is covered by arithmetic.
+    struct Staged {
+        double u, v, pt[3], pp[6];
+    };
+    auto fetch = [&](int c0, int i, Staged &q) {
+        q.u = static_cast<double>(s_uv[(2 * i) * ROW + tid]);
+        q.v = static_cast<double>(s_uv[(2 * i + 1) * ROW + tid]);
+        if constexpr (SHARED) {
+            const double *d = s_pat + 9 * (c0 + i);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) q.pt[k] = d[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) q.pp[k] = d[3 + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) q.pt[k] = static_cast<double>(s_xyz[(3 * i + k) * ROW + tid]);
+        }
+    };
+    auto accumulate = [&](const Staged &q) {
+        const double bx = __builtin_fma(ki.a00, q.u, __builtin_fma(ki.a01, q.v, ki.a02));
+        const double by = __builtin_fma(ki.a10, q.u, __builtin_fma(ki.a11, q.v, ki.a12));
+        if constexpr (SHARED)
+            moments_add_axes(M, q.pp, q.pt, bx, by);
+        else
+            moments_add(M, q.pt[0], q.pt[1], q.pt[2], bx, by);
+    };
     prefetch(0);
     for (int c0 = 0; c0 < N; c0 += C) {
         const int cn = min(C, N - c0);
-        __syncthreads();  // the previous chunk has been consumed (and the shared pattern staged)
+        __syncthreads();  // the previous chunk has been consumed
         commit();
         __syncthreads();
         if (c0 + C < N) prefetch(c0 + C);
         if (tid < nprob) {
+            Staged cur, nxt;
+            fetch(c0, 0, nxt);
+#pragma unroll 1
             for (int i = 0; i < cn; ++i) {
-                const double u = static_cast<double>(s_uv[(2 * i) * ROW + tid]);
-                const double v = static_cast<double>(s_uv[(2 * i + 1) * ROW + tid]);
-                double X, Y, Z;
-                if constexpr (SHARED) {
-                    X = static_cast<double>(s_xyz[3 * (c0 + i)]);
-                    Y = static_cast<double>(s_xyz[3 * (c0 + i) + 1]);
-                    Z = static_cast<double>(s_xyz[3 * (c0 + i) + 2]);
-                } else {
-                    X = static_cast<double>(s_xyz[(3 * i) * ROW + tid]);
-                    Y = static_cast<double>(s_xyz[(3 * i + 1) * ROW + tid]);
-                    Z = static_cast<double>(s_xyz[(3 * i + 2) * ROW + tid]);
-                }
-                const double bx = __builtin_fma(ki.a00, u, __builtin_fma(ki.a01, v, ki.a02));
-                const double by = __builtin_fma(ki.a10, u, __builtin_fma(ki.a11, v, ki.a12));
-                moments_add(M, X, Y, Z, bx, by);
+                cur = nxt;
+                fetch(c0, min(i + 1, cn - 1), nxt);
+                accumulate(cur);
             }
         }
     }

@@ -936,6 +936,23 @@ def test_moment_form_small_residuals_fall_back_to_points(golden, torch_dev, mome
     assert np.array_equal(q["iters"], g["iters"]) and np.abs(q["R"] - g["R"]).max() <= DR_F64
 
 
+def test_moment_form_at_the_largest_n(torch_dev, moment_form):
+    """N = pnp_max_points(): the shared pattern then takes 9 N doubles of LDS and the kernel
+    falls back to its short pixel chunk; both pattern layouts against the point form."""
+    from pnp_solver_test_amd import synth
+    nmax = moment_form.pnp_max_points()
+    rng = np.random.default_rng(5)
+    P = rng.uniform([-0.07, -0.05, -0.04], [0.07, 0.12, 0.02], (nmax, 3))
+    uv, _ = synth.stress_batch(300, seed=9, pattern=P, K=K, is_quantized=True)
+    a = solve_dev64(uv, P, torch_dev)
+    b = solve_dev64(uv, np.broadcast_to(P, (300, nmax, 3)), torch_dev)
+    moment_form.pnp_set_qeif_form(_lib.QEIF_FORM_POINTS)
+    ref = solve_dev64(uv, P, torch_dev)
+    for o in (a, b):
+        assert np.array_equal(o["iters"], ref["iters"])
+        assert np.abs(o["R"] - ref["R"]).max() <= 1e-10 and np.abs(o["t"] - ref["t"]).max() <= 1e-10
+
+
 def test_moment_form_selection_rules(torch_dev):
     lib = _lib.load()
     assert lib.pnp_get_qeif_form(1 << 18, 68) == _lib.QEIF_FORM_MOMENTS
