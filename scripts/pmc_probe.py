@@ -29,6 +29,9 @@ for _ in range(3):
 for _ in range(3):
     pnp.solve_pnp_batch(uv, P6, synth.K_DEFAULT, method="qeif", want_rpy=False)
 for _ in range(3):
-    pnp.solve_pnp_batch(uv68, P68d, synth.K_DEFAULT, method="qeif", want_rpy=False)
+    pnp.solve_pnp_batch(uv68, P68d, synth.K_DEFAULT, method="qeif", want_rpy=False)      # moment form, shared pattern
+own68 = P68d[None].expand(B68, 68, 3).contiguous()
+for _ in range(3):
+    pnp.solve_pnp_batch(uv68, own68, synth.K_DEFAULT, method="qeif", want_rpy=False)     # moment form, own patterns
 torch.cuda.synchronize()
 print("probe done")

@@ -17,10 +17,11 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", "pmc")
 
 # dispatch order of scripts/pmc_probe.py: 3 launches each
-LAUNCHES = [("qeif_n6_b1m_per_problem_xyz", "qeif_kernel<1, 6>", 1 << 20, 6, True),
-            ("dlt_n6_b1m_per_problem_xyz", "dlt_kernel<1, 6>", 1 << 20, 6, True),
-            ("qeif_n6_b1m_shared_pattern", "qeif_kernel<1, 6>", 1 << 20, 6, False),
-            ("qeif_n68_b256k_shared_pattern", "qeif_kernel<4, 0>", 1 << 18, 68, False)]
+LAUNCHES = [("qeif_n6_b1m_per_problem_xyz", "qeif_kernel<1, 6,", 1 << 20, 6, True),
+            ("dlt_n6_b1m_per_problem_xyz", "dlt_kernel<1, 6,", 1 << 20, 6, True),
+            ("qeif_n6_b1m_shared_pattern", "qeif_kernel<1, 6,", 1 << 20, 6, False),
+            ("qeif_n68_b256k_shared_pattern", "qeif_moment_kernel<float, 16, true>", 1 << 18, 68, False),
+            ("qeif_n68_b256k_per_problem_xyz", "qeif_moment_kernel<float, 8, false>", 1 << 18, 68, True)]
 
 
 def load(name):
@@ -66,6 +67,11 @@ for label, kern, B, N, own in LAUNCHES:
     s["write_bytes"] = s["WRITE_SIZE"] * 1024
     s["hbm_bytes_per_launch"] = s["fetch_bytes_2x"] + s["write_bytes"]
     s["fetch_2x_over_input"] = round(s["fetch_bytes_2x"] / in_bytes, 4)
+    if "moment" in kern:
+        # 4-byte-per-lane loads in 64/128-byte runs: the doubling rule is calibrated for 16 B/lane
+        # streaming reads only, so the true read traffic lies between the raw and the doubled figure
+        s["fetch_calibration"] = "uncalibrated access width: between FETCH_SIZE (%.3f x input) and 2 x FETCH_SIZE (%.3f x input)" % (
+            s["fetch_bytes_2x"] / 2 / in_bytes, s["fetch_bytes_2x"] / in_bytes)
     if "SQ_ACTIVE_INST_VALU" in s and "GRBM_GUI_ACTIVE" in s:
         # SQ_* activity counters tick in quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs
         s["valu_busy_frac"] = round(4 * s["SQ_ACTIVE_INST_VALU"] / 1024 / (s["GRBM_GUI_ACTIVE"] / 8), 4)
