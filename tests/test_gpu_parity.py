@@ -965,3 +965,97 @@ def test_moment_form_selection_rules(torch_dev):
     finally:
         lib.pnp_set_lanes_per_problem(0)
     assert lib.pnp_set_qeif_form(7) < 0
+
+
+# ---------------------------------------------------------------------------------------------
+# the C ABI from a C++ program, and from a side stream
+# ---------------------------------------------------------------------------------------------
+
+def test_cpp_consumer_of_the_c_abi(torch_dev):
+    """tests/abi/abi_check (built from abi_check.cpp by the library's Makefile) links
+    libpnp_hip.so and the HIP runtime only: host- and device-pointer calls, both element types."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tests", "abi", "abi_check")
+    assert os.path.exists(exe), "build it with make -C pnp_solver_test_amd/csrc"
+    env = dict(os.environ)
+    env.pop("LD_LIBRARY_PATH", None)        # one HIP runtime in that process: the system one
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi_check passed" in r.stdout
+
+
+def test_launch_on_a_side_stream(golden, torch_dev):
+    """Device-pointer calls enqueue on torch's CURRENT stream: work queued on a side stream behind
+    a long-running producer must see the producer's output."""
+    import torch
+    g, uv = stress_uv6(golden)
+    ref = solve_dev(uv, P6f, torch_dev)
+    side = torch.cuda.Stream(device=torch_dev)
+    src = to_dev(uv, torch_dev)
+    pat = to_dev(P6f, torch_dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        buf = torch.zeros_like(src)
+        for _ in range(50):                       # keep the stream busy, then produce the input
+            buf.add_(1.0)
+        buf.copy_(src)
+        out = pnp.solve_pnp_batch(buf, pat, K)
+    side.synchronize()
+    assert np.array_equal(out["R"].cpu().numpy(), ref["R"]) and np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+
+
+# ---------------------------------------------------------------------------------------------
+# sweep over the number of points: chunk boundaries of the moment kernel, register / LDS paths
+# of the point kernel, both element types, both pattern layouts, all against the C oracle
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("N", [4, 5, 7, 8, 9, 10, 15, 16, 17, 31, 32, 33, 40])
+def test_point_count_sweep_against_oracle(torch_dev, N):
+    from pnp_solver_test_amd import synth
+    lib = _lib.load()
+    rng = np.random.default_rng(100 + N)
+    P = rng.uniform([-0.07, -0.05, -0.04], [0.07, 0.12, 0.02], (N, 3))
+    B = 700
+    uv, _ = synth.stress_batch(B, seed=N, pattern=P, K=K, is_quantized=True)
+    P32 = P.astype(np.float32)
+    ref32 = c_oracle.qeif_batch(uv.astype(np.float64), P32.astype(np.float64), K)
+    ref64 = c_oracle.qeif_batch(uv.astype(np.float64), P, K)
+    own32 = np.broadcast_to(P32, (B, N, 3))
+    for form in (_lib.QEIF_FORM_POINTS, _lib.QEIF_FORM_MOMENTS):
+        lib.pnp_set_qeif_form(form)
+        try:
+            outs32 = [solve_dev(uv, P32, torch_dev), solve_dev(uv, own32, torch_dev)]
+            outs64 = [solve_dev64(uv, P, torch_dev), solve_dev64(uv, np.broadcast_to(P, (B, N, 3)), torch_dev)]
+        finally:
+            lib.pnp_set_qeif_form(_lib.QEIF_FORM_AUTO)
+        for o in outs32:
+            assert np.array_equal(o["iters"], ref32["iters"]), (N, form)
+            assert_tight(o, ref32)
+        for o in outs64:
+            assert np.array_equal(o["iters"], ref64["iters"]), (N, form)
+            assert np.abs(o["R"] - ref64["R"]).max() <= DR_F64 and rel_t(o["t"], ref64["t"]).max() <= RELT_F64
+    d = solve_dev64(uv, P, torch_dev, method="dlt")
+    refd = c_oracle.dlt_batch(uv.astype(np.float64), P, K)
+    clear = np.isfinite(refd["R"]).all(axis=(1, 2)) & (refd["margins"][:, :2].min(axis=1) > 1e-6)
+    if N >= 6 and clear.any():                  # fewer points leave the 4x4 systems close to singular
+        assert np.abs(d["R"] - refd["R"])[clear].max() <= 1e-6
+
+
+@pytest.mark.parametrize("N", [1, 2, 3])
+def test_underdetermined_point_counts_do_not_fault(torch_dev, N):
+    """Fewer than four points cannot fix the six unknowns; the prior keeps the filter's matrices
+    invertible, so the calls must run and return arrays of the right shape (values unspecified)."""
+    lib = _lib.load()
+    uv = np.full((300, N, 2), 100.0, np.float32) + np.arange(N * 2, dtype=np.float32).reshape(N, 2)
+    P = np.linspace(-0.05, 0.05, N * 3, dtype=np.float32).reshape(N, 3)
+    for form in (_lib.QEIF_FORM_POINTS, _lib.QEIF_FORM_MOMENTS):
+        lib.pnp_set_qeif_form(form)
+        try:
+            out = solve_dev(uv, P, torch_dev)
+        finally:
+            lib.pnp_set_qeif_form(_lib.QEIF_FORM_AUTO)
+        assert out["R"].shape == (300, 3, 3) and out["iters"].min() >= 1 and out["iters"].max() <= 14
+    for method in ("dlt", "lm12"):
+        assert solve_dev(uv, P, torch_dev, method=method)["t"].shape == (300, 3)

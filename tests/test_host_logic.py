@@ -216,3 +216,19 @@ def test_golden_pattern_tables_match_the_reference(golden):
     assert np.array_equal(synth.pattern_rows("Alexander", synth.LM6_KEYS), m["xyz"][0])
     assert np.array_equal(synth.pattern_rows("Holly", synth.LM6_KEYS), m["xyz"][1])
     assert np.array_equal(synth.PATTERN6, m["xyz"][0])
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/pnp_hip.h must be consumable from C (the boundary is a C ABI): it compiles as C99
+    on its own, and the symbols it declares link against the built library."""
+    import subprocess
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "pnp_hip.h"\n'
+                   'int main(void) { pnp_qeif_params p; pnp_qeif_default_params(&p);\n'
+                   '  return (p.max_it == 14 && pnp_max_points() >= 68 && pnp_version()[0] == \'p\') ? 0 : 1; }\n')
+    exe = tmp_path / "use_header"
+    libdir = os.path.join(ROOT, "pnp_solver_test_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    str(src), "-L", libdir, "-lpnp_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+                    "-o", str(exe)], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0       # no device needed for these three calls
