@@ -209,7 +209,8 @@ int launch_qeif(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, in
                 int32_t *iters, T *rpy, int32_t *pid)
 {
     if (B == 0) return PNP_OK;
-    if (use_moment_form(B, N, n_patterns)) {
+    // the moment kernel addresses a workgroup's rows with 32-bit offsets: 256 rows of xyz_stride
+    if (use_moment_form(B, N, n_patterns) && xyz_stride <= (int64_t(1) << 22)) {
         if (pid) HIP_TRY(hipMemsetAsync(pid, 0, static_cast<size_t>(B) * sizeof(int32_t), s));
         return launch_qeif_moment<T>(s, uv, xyz, xyz_stride, ki, B, N, p, R, t, res, iters, rpy);
     }
