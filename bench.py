@@ -85,7 +85,47 @@ def cpu_baseline(uv, xyz, K):
     return dict(value=round(n / dt, 1), unit="solves/s", cores=1, kind="port",
                 sample="first %d problems of the workload, NumPy float64 per-problem loop "
                        "(oracle/pnp_oracle.qeif_solve), %.1f s" % (n, dt),
-                host_cpus=os.cpu_count())
+                host_cpus=os.cpu_count(), host=host_description())
+
+
+def host_description():
+    """CPU model and NumPy / BLAS versions of the box the CPU baselines ran on."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    blas = "unknown"
+    try:
+        cfg = np.show_config(mode="dicts")
+        dep = cfg.get("Build Dependencies", {}).get("blas", {})
+        blas = "%s %s" % (dep.get("name", "?"), dep.get("version", "?"))
+    except Exception:
+        pass
+    return "%s; numpy %s; %s" % (model, np.__version__, blas)
+
+
+def cpu_baseline_c_threads(uv, xyz, K, threads):
+    """The scalar C restatement on `threads` host threads, one contiguous slice each (the C call
+    releases the interpreter lock; problems are independent)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import c_oracle
+    n = min(len(uv), 1 << 20)
+    u64, x64 = uv[:n].astype(np.float64), xyz[:n].astype(np.float64)
+    bounds = [(i * n // threads, (i + 1) * n // threads) for i in range(threads)]
+    c_oracle.qeif_batch(u64[:64], x64[:64], K)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(lambda b: c_oracle.qeif_batch(u64[b[0]:b[1]], x64[b[0]:b[1]], K), bounds))
+    dt = time.perf_counter() - t0
+    return dict(value=round(n / dt, 1), unit="solves/s", cores=threads, kind="port",
+                sample="first %d problems in %d slices, scalar C float64 (oracle/pnp_oracle.c), one thread per "
+                       "slice, %.2f s" % (n, threads, dt))
 
 
 def cpu_baseline_c(uv, xyz, K):
@@ -283,6 +323,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:   # last: the GPU idles (and clocks down) meanwhile
             line["cpu_baseline"] = cpu_baseline(uv_h, xyz_h, K)
             line["cpu_baseline_c"] = cpu_baseline_c(uv_h, xyz_h, K)
+            threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+            line["cpu_baseline_c_all_cores"] = cpu_baseline_c_threads(uv_h, xyz_h, K, threads)
         print(json.dumps(line), flush=True)
 
     if distributed:
