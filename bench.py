@@ -143,7 +143,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=BATCH, help="problems per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
@@ -206,6 +206,25 @@ def main():
     iters_mean = float(out["iters"].float().mean().item())
     ok = bool(torch.isfinite(out["R"]).all().item())
 
+    # The optional exchange: every rank ends up with every rank's poses (R, t: 48 B per problem)
+    # through RCCL all-gather.  Reported beside the headline, never part of it.
+    gather = None
+    if distributed:
+        g_steps = max(5, args.steps // 10)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(g_steps):
+            o = step()
+            full = pnp.gather_results({"R": o["R"], "t": o["t"]})
+        barrier()
+        g_elapsed = time.perf_counter() - t0
+        gmax = torch.tensor([g_elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(gmax, op=dist.ReduceOp.MAX)
+        gather = dict(solves_per_s=round(world * B * g_steps / float(gmax.item()), 1), steps=g_steps,
+                      ms_per_step=round(float(gmax.item()) / g_steps * 1e3, 4),
+                      gathered_bytes_per_rank_per_step=int(full["R"].numel() * 4 + full["t"].numel() * 4),
+                      what="solve + all_gather_into_tensor of R and t (RCCL)")
+
     if rank == 0:
         total = world * B * args.steps
         value = total / elapsed
@@ -263,6 +282,8 @@ def main():
                 "flops_per_solve": round(flops, 1),
             },
         }
+        if gather is not None:
+            line["with_result_gather"] = gather
         if world == 1 and not args.no_other_configs:
             other = {}
             n_small = max(5, min(50, args.steps // 2))
