@@ -1,0 +1,197 @@
+// Shared device definitions of the batched PnP solvers for CDNA4 (gfx950): launch constants,
+// parameter structs, exact reciprocal / square root, small symmetric linear algebra held in
+// registers, the wavefront group sum, Euler angles, and the global -> LDS copy.  All float64.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pnp {
+
+constexpr int kBlock = 256;
+// Threads per workgroup of the solver kernels for element type T: 256 for float, 128 for double,
+// so that a workgroup's staged correspondences take the same LDS bytes either way.
+template <typename T>
+constexpr int kSolveBlock = kBlock * static_cast<int>(sizeof(float)) / static_cast<int>(sizeof(T));
+
+#ifndef PNP_QEIF_WAVES
+#define PNP_QEIF_WAVES 2  // minimum resident waves per SIMD the QEIF kernels are compiled for
+#endif
+
+struct KinvRows {  // first two rows of K^-1: nu_x = a00 u + a01 v + a02, nu_y = a10 u + a11 v + a12
+    double a00, a01, a02, a10, a11, a12;
+};
+
+struct Mat3 {  // row-major 3x3, passed to kernels by value
+    double m[9];
+};
+
+struct QeifParams {
+    double q_inv, r_quat, r_delta, omega0, rel_tol, res_old0;
+    int max_it;
+};
+
+// ------------------------------------------------------------------------------------------
+// scalar helpers
+// ------------------------------------------------------------------------------------------
+
+// 1/d to full double precision.  The hardware seed r0 of v_rcp_f64 carries a relative error
+// e = 1 - d r0 of about 5e-8; 1/d = r0 (1 + e + e^2 + ...), and r0 (1 + e + e^2) leaves e^3 ~
+// 1e-22, below rounding.  d == 0 or non-finite input propagates NaN/inf.
+__device__ __forceinline__ double rcp(double d)
+{
+    const double r0 = __builtin_amdgcn_rcp(d);
+    const double e = __builtin_fma(-d, r0, 1.0);
+    return __builtin_fma(__builtin_fma(e, e, e), r0, r0);
+}
+
+// sqrt(x) for 0 <= x in the normal range: hardware reciprocal-square-root seed, one coupled
+// Goldschmidt step and one residual correction (error of a few 1e-16 relative).  x == 0 gives
+// 0, x < 0 or NaN gives NaN; no rescaling of subnormal or huge arguments (not met here).
+__device__ __forceinline__ double sqrt_pos(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return (x == 0.0) ? 0.0 : g;
+}
+
+__device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // i >= j
+
+// In-place symmetric sweep of every pivot: a <- -(a^-1) for a symmetric definite n x n
+// matrix held as its packed lower triangle (a[tri(i,j)], i >= j).  Sweeping pivot k maps
+//   a_kk -> -1/a_kk,  a_ik -> a_ik/a_kk,  a_ij -> a_ij - a_ik a_jk / a_kk   (i, j != k)
+// which keeps the matrix symmetric at every step, so the whole inversion runs in the 21
+// registers of the packed triangle plus one column of temporaries.  Works for positive and
+// for negative definite input alike (no pivoting is needed in either case).
+template <int n>
+__device__ __forceinline__ void sweep_neg_inverse(double (&a)[n * (n + 1) / 2])
+{
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+        const double dinv = rcp(a[tri(k, k)]);
+        double t[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+            if (i != k) t[i] = a[i > k ? tri(i, k) : tri(k, i)] * dinv;
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            if (i == k) continue;
+            const double aik = a[i > k ? tri(i, k) : tri(k, i)];
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                if (j == k) continue;
+                a[tri(i, j)] = __builtin_fma(-aik, t[j], a[tri(i, j)]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+            if (i != k) a[i > k ? tri(i, k) : tri(k, i)] = t[i];
+        a[tri(k, k)] = -dinv;
+    }
+}
+
+// Solves M x = b1 and M x = b2 for a packed SPD n x n matrix (LDL^T, two right-hand sides).
+template <int n>
+__device__ __forceinline__ void spd_solve2(const double (&m)[n * (n + 1) / 2], double (&b1)[n],
+                                           double (&b2)[n])
+{
+    double L[n][n], W[n][n], dinv[n];
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+        double s = m[tri(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s = __builtin_fma(-W[j][k], L[j][k], s);
+        dinv[j] = rcp(s);
+#pragma unroll
+        for (int i = j + 1; i < n; ++i) {
+            double v = m[tri(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v = __builtin_fma(-W[i][k], L[j][k], v);
+            W[i][j] = v;
+            L[i][j] = v * dinv[j];
+        }
+    }
+#pragma unroll
+    for (int i = 1; i < n; ++i) {  // forward substitution, unit lower
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+            b1[i] = __builtin_fma(-L[i][k], b1[k], b1[i]);
+            b2[i] = __builtin_fma(-L[i][k], b2[k], b2[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+        b1[i] *= dinv[i];
+        b2[i] *= dinv[i];
+    }
+#pragma unroll
+    for (int i = n - 2; i >= 0; --i) {  // back substitution with L^T
+#pragma unroll
+        for (int k = i + 1; k < n; ++k) {
+            b1[i] = __builtin_fma(-L[k][i], b1[k], b1[i]);
+            b2[i] = __builtin_fma(-L[k][i], b2[k], b2[i]);
+        }
+    }
+}
+
+// Sum of v over the LPI lanes of a problem (xor butterfly); every lane gets the total.
+template <int LPI>
+__device__ __forceinline__ double group_sum(double v)
+{
+#pragma unroll
+    for (int m = LPI / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// roll, yaw, pitch (degrees) of a rotation matrix, reference conventions: gimbal-lock
+// branch when |pi/2 - asin|R21|| <= 1e-7, c2 taken from the better-conditioned of
+// R11/cos(th1) and R22/cos(th3), yaw sign flipped.
+__device__ __forceinline__ void euler_deg(const double (&R)[9], double &roll, double &yaw,
+                                          double &pitch)
+{
+    constexpr double kPi = 3.14159265358979323846;
+    constexpr double kHalfPi = kPi / 2.0;
+    constexpr double kR2D = 180.0 / kPi;
+    double th1, th2, th3;
+    if (fabs(kHalfPi - asin(fabs(R[7]))) <= 1e-7) {
+        const double s = (-R[7] > 0.0) ? 1.0 : ((-R[7] < 0.0) ? -1.0 : 0.0);
+        th2 = s * kHalfPi;
+        th3 = 0.0;
+        th1 = atan2(-R[3], R[0]);
+    } else {
+        th1 = atan2(R[1], R[4]);
+        th3 = atan2(R[6], R[8]);
+        const double c1 = cos(th1), c3 = cos(th3);
+        const double c2 = (fabs(c1) > fabs(c3)) ? R[4] / c1 : R[8] / c3;
+        th2 = atan2(-R[7], c2);
+    }
+    roll = th1 * kR2D;
+    yaw = -(th3 * kR2D);
+    pitch = th2 * kR2D;
+}
+
+// ------------------------------------------------------------------------------------------
+// staging: contiguous global range -> LDS, 16 bytes per lane when alignment allows
+// ------------------------------------------------------------------------------------------
+
+template <int BLOCK = kBlock, typename T>
+__device__ __forceinline__ void stage_elems(T *dst, const T *src, int count, int tid)
+{
+    constexpr int per16 = 16 / static_cast<int>(sizeof(T));
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const int n16 = count / per16;
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+        for (int i = tid; i < n16; i += BLOCK) d4[i] = s4[i];
+        for (int i = n16 * per16 + tid; i < count; i += BLOCK) dst[i] = src[i];
+    } else {
+        for (int i = tid; i < count; i += BLOCK) dst[i] = src[i];
+    }
+}
+
+}  // namespace pnp

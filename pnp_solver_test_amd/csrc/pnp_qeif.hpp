@@ -1,0 +1,428 @@
+// QEIF, the quaternion iterated information filter (the live solver): point form (every
+// iteration visits every point) and moment form (sums over the points formed once).
+#pragma once
+
+#include "pnp_common.hpp"
+
+namespace pnp {
+
+// ------------------------------------------------------------------------------------------
+// QEIF: quaternion iterated information filter (damped Gauss-Newton on [q, delta1, delta2])
+// ------------------------------------------------------------------------------------------
+
+// One point's contribution to the information matrix, the gradient and the squared residual.
+//
+// Everything is carried in units scaled by c = sqrt(q_inv), so that the products land in the
+// information matrix Omega = Obar + q_inv H^T H without a separate scaling pass:
+//   qs[4] = c * 2q,  hq[4] = q / 2
+//   s~ = c * s with  p^T Q1 = [s0 s1 s2 s3], p^T Q2 = [-s3 -s2 s1 s0], p^T Q3 = [s2 -s3 -s0 s1]
+//        (the three 3x4 Jacobians d(phi_j)/dq share these four products of the point with 2q)
+//   c * P phi_j = (p^T Q_j) . q / 2           (phi_j is a quadratic form in q)
+//   u~ = c (p^T Q1 - bx p^T Q3), v~ = c (p^T Q2 - by p^T Q3): rows H_x = [u, 1, 0], H_y = [v, 0, 1]
+//   r~ = c (z - h)
+// M receives q_inv H^T H in its (q,q), (d1,q) and (d2,q) entries (packed lower 6x6; the
+// constant (d,d) block q_inv*N*I is added by the caller); g receives [c^2 H_q^T r, c r_x, c r_y]
+// summed, ss the sum of c^2 r^2.
+__device__ __forceinline__ void qeif_point(double (&M)[21], double (&g)[6], double &ss,
+                                           const double (&qs)[4], const double (&hq)[4], double c,
+                                           double d1, double d2, double X, double Y, double Z,
+                                           double bx, double by)
+{
+    const double s0 = __builtin_fma(X, qs[0], __builtin_fma(-Y, qs[3], Z * qs[2]));
+    const double s1 = __builtin_fma(X, qs[1], __builtin_fma(Y, qs[2], Z * qs[3]));
+    const double s2 = __builtin_fma(-X, qs[2], __builtin_fma(Y, qs[1], Z * qs[0]));
+    const double s3 = __builtin_fma(-X, qs[3], __builtin_fma(-Y, qs[0], Z * qs[1]));
+    const double p1 = __builtin_fma(s0, hq[0], __builtin_fma(s1, hq[1], __builtin_fma(s2, hq[2], s3 * hq[3])));
+    const double p2 = __builtin_fma(-s3, hq[0], __builtin_fma(-s2, hq[1], __builtin_fma(s1, hq[2], s0 * hq[3])));
+    const double p3 = __builtin_fma(s2, hq[0], __builtin_fma(-s3, hq[1], __builtin_fma(-s0, hq[2], s1 * hq[3])));
+    const double rx = __builtin_fma(c, bx - d1, -__builtin_fma(-bx, p3, p1));
+    const double ry = __builtin_fma(c, by - d2, -__builtin_fma(-by, p3, p2));
+    double u[4], v[4];
+    u[0] = __builtin_fma(-bx, s2, s0);
+    u[1] = __builtin_fma(bx, s3, s1);
+    u[2] = __builtin_fma(bx, s0, s2);
+    u[3] = __builtin_fma(-bx, s1, s3);
+    v[0] = __builtin_fma(-by, s2, -s3);
+    v[1] = __builtin_fma(by, s3, -s2);
+    v[2] = __builtin_fma(by, s0, s1);
+    v[3] = __builtin_fma(-by, s1, s0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j)
+            M[tri(i, j)] = __builtin_fma(u[i], u[j], __builtin_fma(v[i], v[j], M[tri(i, j)]));
+        M[tri(4, i)] = __builtin_fma(c, u[i], M[tri(4, i)]);
+        M[tri(5, i)] = __builtin_fma(c, v[i], M[tri(5, i)]);
+        g[i] = __builtin_fma(u[i], rx, __builtin_fma(v[i], ry, g[i]));
+    }
+    g[4] += rx;
+    g[5] += ry;
+    ss = __builtin_fma(rx, rx, __builtin_fma(ry, ry, ss));
+}
+
+// Gamma(q) = |q|^2 R(q), row-major, and gamma = |q|^2
+__device__ __forceinline__ void gamma_matrix(const double (&x)[6], double (&phi)[9], double &gamma)
+{
+    const double qr = x[0], qi = x[1], qj = x[2], qk = x[3];
+    gamma = __builtin_fma(qr, qr, __builtin_fma(qi, qi, __builtin_fma(qj, qj, qk * qk)));
+    const double qii = qi * qi, qjj = qj * qj, qkk = qk * qk;
+    const double qij = qi * qj, qjk = qj * qk, qik = qi * qk;
+    const double qri = qr * qi, qrj = qr * qj, qrk = qr * qk;
+    phi[0] = gamma - 2.0 * (qjj + qkk);
+    phi[1] = 2.0 * (qij - qrk);
+    phi[2] = 2.0 * (qik + qrj);
+    phi[3] = 2.0 * (qij + qrk);
+    phi[4] = gamma - 2.0 * (qii + qkk);
+    phi[5] = 2.0 * (qjk - qri);
+    phi[6] = 2.0 * (qik - qrj);
+    phi[7] = 2.0 * (qjk + qri);
+    phi[8] = gamma - 2.0 * (qii + qjj);
+}
+
+// One problem's full solve as seen by one of its LPI lanes.  `pts(i, X, Y, Z, bx, by)`
+// fetches point i; this lane visits points lane_in_group, lane_in_group + LPI, ...
+//
+// Recurrence (exact restatement of the information-filter loop, rearranged):
+//   Sigma_0 = I/omega0, x_0 = [1,0,0,0,0,0]
+//   each iteration:  Obar = (Sigma + R_p)^-1               (both inverses: symmetric sweeps)
+//                    Omega = Obar + q_inv * H^T H          H, r = z - h at the current x
+//                    res   = |r|                           (residual BEFORE the update)
+//                    Sigma = Omega^-1 ;  x += Sigma * (q_inv * H^T r)
+//                    stop if |res - res_old| < rel_tol * res_old, else res_old = res
+// The reference forms zeta = Obar x + q_inv H^T (z - h + H x) and x = Sigma zeta; since
+// Omega = Obar + q_inv H^T H these are the same vector, x + Sigma q_inv H^T (z - h).
+// Its stopping rule |(res - res_old)/res_old| < rel_tol is the same inequality (res_old > 0).
+struct QeifState {
+    double x[6];     // [q(4), delta1, delta2]
+    double T[21];    // packed lower 6x6; holds -Sigma between iterations (see qeif_iterate)
+    double res_old;  // residual norm of the previous iteration
+    double res;      // residual norm at the last linearisation point
+    int k;           // iterations done
+};
+
+__device__ __forceinline__ void qeif_init(QeifState &st, const QeifParams &p)
+{
+    st.x[0] = 1.0;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) st.x[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 21; ++i) st.T[i] = 0.0;
+    const double s0 = -1.0 / p.omega0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) st.T[tri(i, i)] = s0;
+    st.res_old = p.res_old0;
+    st.res = 1.0e5;
+    st.k = 0;
+}
+
+// Scalars derived from the parameters once per kernel.
+struct QeifConsts {
+    double c, c_inv, dd;  // sqrt(q_inv), its reciprocal, q_inv * N
+    __device__ __forceinline__ QeifConsts(const QeifParams &p, int N)
+        : c(sqrt(p.q_inv)), c_inv(1.0 / sqrt(p.q_inv)), dd(p.q_inv * static_cast<double>(N)) {}
+};
+
+// One iteration; returns true when the stopping rule fires.  T is swept twice and changes
+// sign each time: -Sigma on entry, Obar after the first sweep, -Sigma again on exit.
+template <int LPI, int NCT, typename PointFetch>
+__device__ __forceinline__ bool qeif_iterate(QeifState &st, const PointFetch &pts, int N, int lane_in_group,
+                                             const QeifParams &p, const QeifConsts &kc)
+{
+    double(&x)[6] = st.x;
+    double(&T)[21] = st.T;
+    const double c = kc.c;
+    ++st.k;
+    // predict: -(Sigma + R_p), then sweep -> (Sigma + R_p)^-1 = Obar
+#pragma unroll
+    for (int i = 0; i < 4; ++i) T[tri(i, i)] -= p.r_quat;
+    T[tri(4, 4)] -= p.r_delta;
+    T[tri(5, 5)] -= p.r_delta;
+    sweep_neg_inverse<6>(T);
+    // update: Omega = Obar + q_inv H^T H, accumulated point by point
+    const double qs[4] = {2.0 * c * x[0], 2.0 * c * x[1], 2.0 * c * x[2], 2.0 * c * x[3]};
+    const double hq[4] = {0.5 * x[0], 0.5 * x[1], 0.5 * x[2], 0.5 * x[3]};
+    double g[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double ss = 0.0;
+    if constexpr (LPI == 1) {
+        if constexpr (NCT > 0) {  // the lane owns all NCT points, held in registers
+#pragma unroll
+            for (int i = 0; i < NCT; ++i) {
+                double X, Y, Z, bx, by;
+                pts(i, X, Y, Z, bx, by);
+                qeif_point(T, g, ss, qs, hq, c, x[4], x[5], X, Y, Z, bx, by);
+            }
+        } else {
+            for (int i = 0; i < N; ++i) {
+                double X, Y, Z, bx, by;
+                pts(i, X, Y, Z, bx, by);
+                qeif_point(T, g, ss, qs, hq, c, x[4], x[5], X, Y, Z, bx, by);
+            }
+        }
+    } else {
+        double M[21];  // this lane's share; only the (q,q), (d1,q), (d2,q) entries are used
+#pragma unroll
+        for (int i = 0; i < 21; ++i) M[i] = 0.0;
+        for (int i = lane_in_group; i < N; i += LPI) {
+            double X, Y, Z, bx, by;
+            pts(i, X, Y, Z, bx, by);
+            qeif_point(M, g, ss, qs, hq, c, x[4], x[5], X, Y, Z, bx, by);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) T[tri(i, j)] += group_sum<LPI>(M[tri(i, j)]);
+            T[tri(4, i)] += group_sum<LPI>(M[tri(4, i)]);
+            T[tri(5, i)] += group_sum<LPI>(M[tri(5, i)]);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) g[i] = group_sum<LPI>(g[i]);
+        ss = group_sum<LPI>(ss);
+    }
+    T[tri(4, 4)] += kc.dd;
+    T[tri(5, 5)] += kc.dd;
+    g[4] *= c;
+    g[5] *= c;
+    st.res = sqrt_pos(ss) * kc.c_inv;
+    sweep_neg_inverse<6>(T);  // T = -Sigma
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double dx = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) dx = __builtin_fma(T[i >= j ? tri(i, j) : tri(j, i)], g[j], dx);
+        x[i] -= dx;
+    }
+    const bool stop = fabs(st.res - st.res_old) < p.rel_tol * st.res_old;
+    st.res_old = st.res;
+    return stop;
+}
+
+// reconstruct: R = Gamma(q)/gamma, t3 = 1/gamma, t = [d1, d2, 1] t3
+__device__ __forceinline__ void qeif_finish(const QeifState &st, double (&R)[9], double (&t)[3])
+{
+    double phi[9], gamma;
+    gamma_matrix(st.x, phi, gamma);
+    const double t3 = 1.0 / gamma;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = phi[i] * t3;
+    t[0] = st.x[4] * t3;
+    t[1] = st.x[5] * t3;
+    t[2] = t3;
+}
+
+template <int LPI, int NCT, typename PointFetch>
+__device__ __forceinline__ void qeif_solve(const PointFetch &pts, int N, int lane_in_group,
+                                           const QeifParams &p, double (&R)[9], double (&t)[3],
+                                           double &res_out, int &iters_out)
+{
+    QeifState st;
+    qeif_init(st, p);
+    const QeifConsts kc(p, N);
+    while (st.k < p.max_it) {
+        if (qeif_iterate<LPI, NCT>(st, pts, N, lane_in_group, p, kc)) break;
+    }
+    qeif_finish(st, R, t);
+    res_out = st.res;
+    iters_out = st.k;
+}
+
+// ------------------------------------------------------------------------------------------
+// QEIF in moment form, for problems with many points
+// ------------------------------------------------------------------------------------------
+//
+// H^T H, H^T r and |r|^2 of the QEIF model are polynomials in the state whose coefficients are
+// sums over the points of products of (p, b p, b^2 p, b, b^2), b = nu_x or nu_y of the point:
+//   row of H_x:  a = Q1^T p - bx Q3^T p          residual  r = bx (1 + p.phi3) - p.phi1 - d1
+// so that, with S0 = sum p p^T, S1 = sum b p p^T, S2 = sum b^2 p p^T, m0 = sum p, m1 = sum b p,
+// m2 = sum b^2 p, b1 = sum b, b2 = sum b^2 (per axis),
+//   sum a a^T = Qa^T (S0 Qa - S1 Q3) - Q3^T (S1 Qa - S2 Q3)
+//   sum a     = Qa^T m0 - Q3^T m1
+//   sum a r   = Qa^T (m1 - S0 phia + S1 phi3 - d m0) - Q3^T (m2 - S1 phia + S2 phi3 - d m1)
+//   sum r     = b1 - m0.phia + m1.phi3 - n d
+//   sum r^2   = (b2 + 2 m2.phi3 + phi3^T S2 phi3) - 2 (m1.phia + d b1 + phi3^T S1 phia + d m1.phi3)
+//               + (phia^T S0 phia + 2 d m0.phia + n d^2)
+// (Qa, phia = Q1, phi1 for the x rows and Q2, phi2 for the y rows).  The 50 sums are formed
+// once per problem; an iteration then costs about 700 fused operations whatever N is, against
+// 78 N for the point-by-point form, which pays from N of about 16 upwards.
+//
+// sum r^2 is a difference of large terms: its rounding noise is about 2e-15 (b2x + b2y).  When
+// it comes out below kMomentResidualFloor (b2x + b2y) the residual is recomputed point by point
+// from global memory, so the 1 % stopping rule always sees a residual good to 1e-6 or better.
+// On pixel-quantised or noisy input that branch is never taken.
+
+constexpr double kMomentResidualFloor = 1e-8;
+
+struct AxisMoments {
+    double S1[6], S2[6], m1[3], m2[3], b1, b2;  // S*: packed lower 3x3
+};
+
+struct Moments {
+    double S0[6], m0[3];
+    AxisMoments ax, ay;
+};
+
+__device__ __forceinline__ void moments_clear(Moments &M)
+{
+#pragma unroll
+    for (int i = 0; i < 6; ++i) M.S0[i] = M.ax.S1[i] = M.ax.S2[i] = M.ay.S1[i] = M.ay.S2[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) M.m0[i] = M.ax.m1[i] = M.ax.m2[i] = M.ay.m1[i] = M.ay.m2[i] = 0.0;
+    M.ax.b1 = M.ax.b2 = M.ay.b1 = M.ay.b2 = 0.0;
+}
+
+__device__ __forceinline__ void axis_moments_add(AxisMoments &A, const double (&pp)[6], const double (&pt)[3],
+                                                 double b)
+{
+    const double bb = b * b;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        A.S1[i] = __builtin_fma(b, pp[i], A.S1[i]);
+        A.S2[i] = __builtin_fma(bb, pp[i], A.S2[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        A.m1[i] = __builtin_fma(b, pt[i], A.m1[i]);
+        A.m2[i] = __builtin_fma(bb, pt[i], A.m2[i]);
+    }
+    A.b1 += b;
+    A.b2 += bb;
+}
+
+// The pixel-dependent sums only; pp = packed lower p p^T, pt = p.
+__device__ __forceinline__ void moments_add_axes(Moments &M, const double (&pp)[6], const double (&pt)[3],
+                                                 double bx, double by)
+{
+    axis_moments_add(M.ax, pp, pt, bx);
+    axis_moments_add(M.ay, pp, pt, by);
+}
+
+__device__ __forceinline__ void moments_add(Moments &M, double X, double Y, double Z, double bx, double by)
+{
+    const double pt[3] = {X, Y, Z};
+    const double pp[6] = {X * X, Y * X, Y * Y, Z * X, Z * Y, Z * Z};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) M.S0[i] += pp[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) M.m0[i] += pt[i];
+    axis_moments_add(M.ax, pp, pt, bx);
+    axis_moments_add(M.ay, pp, pt, by);
+}
+
+// y = S v for a packed symmetric 3x3
+__device__ __forceinline__ void sym3_mul(const double (&S)[6], const double (&v)[3], double (&y)[3])
+{
+    y[0] = __builtin_fma(S[0], v[0], __builtin_fma(S[1], v[1], S[3] * v[2]));
+    y[1] = __builtin_fma(S[1], v[0], __builtin_fma(S[2], v[1], S[4] * v[2]));
+    y[2] = __builtin_fma(S[3], v[0], __builtin_fma(S[4], v[1], S[5] * v[2]));
+}
+
+__device__ __forceinline__ double dot3(const double (&a)[3], const double (&b)[3])
+{
+    return __builtin_fma(a[0], b[0], __builtin_fma(a[1], b[1], a[2] * b[2]));
+}
+
+// One axis' share of H^T H (AA: packed lower 4x4, accumulated), sum a, sum a r, sum r, sum r^2.
+// Qa and Q3 are 3x4 (derivatives of phia, phi3 with respect to q).
+__device__ __forceinline__ void moment_axis_terms(const double (&S0)[6], const double (&m0)[3], double n,
+                                                  const AxisMoments &A, const double (&Qa)[3][4],
+                                                  const double (&Q3)[3][4], const double (&phia)[3],
+                                                  const double (&phi3)[3], double d, double (&AA)[10],
+                                                  double (&sa)[4], double (&ga)[4], double &gd, double &rr)
+{
+    double s0a[3], s1a[3], s13[3], s23[3], w1[3], w2[3];
+    sym3_mul(S0, phia, s0a);
+    sym3_mul(A.S1, phia, s1a);
+    sym3_mul(A.S1, phi3, s13);
+    sym3_mul(A.S2, phi3, s23);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        w1[k] = __builtin_fma(-d, m0[k], (A.m1[k] - s0a[k]) + s13[k]);
+        w2[k] = __builtin_fma(-d, A.m1[k], (A.m2[k] - s1a[k]) + s23[k]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double qa[3] = {Qa[0][j], Qa[1][j], Qa[2][j]};
+        const double q3[3] = {Q3[0][j], Q3[1][j], Q3[2][j]};
+        double u0[3], u1[3], v0[3], v1[3];
+        sym3_mul(S0, qa, u0);
+        sym3_mul(A.S1, q3, u1);
+        sym3_mul(A.S1, qa, v0);
+        sym3_mul(A.S2, q3, v1);
+        const double U[3] = {u0[0] - u1[0], u0[1] - u1[1], u0[2] - u1[2]};
+        const double V[3] = {v0[0] - v1[0], v0[1] - v1[1], v0[2] - v1[2]};
+#pragma unroll
+        for (int i = j; i < 4; ++i) {
+            const double qi[3] = {Qa[0][i], Qa[1][i], Qa[2][i]};
+            const double ri[3] = {Q3[0][i], Q3[1][i], Q3[2][i]};
+            AA[tri(i, j)] += dot3(qi, U) - dot3(ri, V);
+        }
+        sa[j] = dot3(qa, m0) - dot3(q3, A.m1);
+        ga[j] = dot3(qa, w1) - dot3(q3, w2);
+    }
+    const double m1p3 = dot3(A.m1, phi3), m0pa = dot3(m0, phia);
+    gd = __builtin_fma(-n, d, (A.b1 - m0pa) + m1p3);
+    const double t_bb = __builtin_fma(2.0, dot3(A.m2, phi3), A.b2) + dot3(phi3, s23);
+    const double t_bf = __builtin_fma(d, A.b1 + m1p3, dot3(A.m1, phia)) + dot3(phi3, s1a);
+    const double t_ff = __builtin_fma(d, __builtin_fma(n, d, 2.0 * m0pa), dot3(phia, s0a));
+    rr = __builtin_fma(-2.0, t_bf, t_bb) + t_ff;
+}
+
+// One iteration from the moments; same state and recurrence as qeif_iterate.  exact_ss()
+// returns the point-by-point sum of squared residuals at the current x.
+template <typename ExactResidual>
+__device__ __forceinline__ bool qeif_moment_iterate(QeifState &st, const Moments &M, double n,
+                                                    const QeifParams &p, const ExactResidual &exact_ss)
+{
+    double(&x)[6] = st.x;
+    double(&T)[21] = st.T;
+    ++st.k;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) T[tri(i, i)] -= p.r_quat;
+    T[tri(4, 4)] -= p.r_delta;
+    T[tri(5, 5)] -= p.r_delta;
+    sweep_neg_inverse<6>(T);  // Obar
+
+    double phi[9], gamma;
+    gamma_matrix(x, phi, gamma);
+    const double a = 2.0 * x[0], b = 2.0 * x[1], c = 2.0 * x[2], d = 2.0 * x[3];
+    const double Q1[3][4] = {{a, b, -c, -d}, {-d, c, b, -a}, {c, d, a, b}};
+    const double Q2[3][4] = {{d, c, b, a}, {a, -b, c, -d}, {-b, -a, d, c}};
+    const double Q3[3][4] = {{-c, d, -a, b}, {b, a, d, c}, {a, -b, -c, d}};
+    const double phi1[3] = {phi[0], phi[1], phi[2]};
+    const double phi2[3] = {phi[3], phi[4], phi[5]};
+    const double phi3[3] = {phi[6], phi[7], phi[8]};
+    double AA[10], sax[4], say[4], gax[4], gay[4], gdx, gdy, rrx, rry;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) AA[i] = 0.0;
+    moment_axis_terms(M.S0, M.m0, n, M.ax, Q1, Q3, phi1, phi3, x[4], AA, sax, gax, gdx, rrx);
+    moment_axis_terms(M.S0, M.m0, n, M.ay, Q2, Q3, phi2, phi3, x[5], AA, say, gay, gdy, rry);
+    double ss = rrx + rry;
+    if (!(ss >= kMomentResidualFloor * (M.ax.b2 + M.ay.b2))) ss = exact_ss(x);
+
+    // Omega = Obar + q_inv H^T H
+    const double w = p.q_inv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) T[tri(i, j)] = __builtin_fma(w, AA[tri(i, j)], T[tri(i, j)]);
+        T[tri(4, i)] = __builtin_fma(w, sax[i], T[tri(4, i)]);
+        T[tri(5, i)] = __builtin_fma(w, say[i], T[tri(5, i)]);
+    }
+    T[tri(4, 4)] = __builtin_fma(w, n, T[tri(4, 4)]);
+    T[tri(5, 5)] = __builtin_fma(w, n, T[tri(5, 5)]);
+    const double g[6] = {w * (gax[0] + gay[0]), w * (gax[1] + gay[1]), w * (gax[2] + gay[2]),
+                         w * (gax[3] + gay[3]), w * gdx, w * gdy};
+    st.res = sqrt_pos(ss);
+    sweep_neg_inverse<6>(T);  // -Sigma
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double dx = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) dx = __builtin_fma(T[i >= j ? tri(i, j) : tri(j, i)], g[j], dx);
+        x[i] -= dx;
+    }
+    const bool stop = fabs(st.res - st.res_old) < p.rel_tol * st.res_old;
+    st.res_old = st.res;
+    return stop;
+}
+
+}  // namespace pnp
