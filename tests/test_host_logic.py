@@ -59,6 +59,21 @@ def test_argument_errors_come_back_as_codes_with_messages():
     assert b"singular" in lib.pnp_last_error()
     assert lib.pnp_set_lanes_per_problem(3) == -1
     assert lib.pnp_set_lanes_per_problem(0) == 0
+    # the float64 flavour, the generator, the comparison epilogue and the form switch check alike
+    assert lib.pnp_qeif_batch_f64(a, a, 0, Kc, 1, pnp._lib.load().pnp_max_points() + 1, None, a, a, None, None, None,
+                                  0, None) == -1
+    assert lib.pnp_lm12_batch_f64(a, a, 0, Kc, 1, 6, -1.0, 14, a, a, None, None, 0, None) == -1
+    assert b"lambda" in lib.pnp_last_error()
+    assert lib.pnp_qeif_multi_batch_f32(a, a, 0, Kc, 1, 6, None, a, a, None, None, None, None, 0, None) == -1
+    assert b"n_patterns" in lib.pnp_last_error()
+    assert lib.pnp_project_batch_f64(a, a, a, 0, Kc, 1, 6, -1.0, a, 0, 0, None) == -1
+    assert b"quantize_q" in lib.pnp_last_error()
+    assert lib.pnp_compare_batch_f32(a, a, None, a, a, a, Kc, 1, 0, None, 1, a, None, None, None, 0, None) == -1
+    assert lib.pnp_compare_batch_f64(a, a, None, a, a, a, Kc, 1, 15, None, 1, None, None, None, None, 0, None) == -1
+    assert b"no output" in lib.pnp_last_error()
+    assert lib.pnp_set_qeif_form(9) == -1 and lib.pnp_set_qeif_form(_lib.QEIF_FORM_AUTO) == 0
+    assert lib.pnp_get_qeif_form(1 << 18, 68) == _lib.QEIF_FORM_MOMENTS
+    assert lib.pnp_get_qeif_form(1 << 20, 6) == _lib.QEIF_FORM_POINTS
     # an empty batch is a no-op, not an error, and touches no device
     assert lib.pnp_qeif_batch_f32(None, None, 0, Kc, 0, 6, None, None, None, None, None, None, 0, None) == 0
     assert lib.pnp_euler_deg_f32(None, 0, None, 0, None) == 0
