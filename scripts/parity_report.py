@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Full-size parity of the HIP path against the C oracle (test infrastructure) at the batch
+sizes of the baseline configurations: every problem of the batch is solved by both, the oracle
+on the host's threads.  Writes max / p99 / median of the rotation angle and the relative
+translation error, and the iteration-count mismatches, to gpurun_out/parity_report.json."""
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import pnp_solver_test_amd as pnp  # noqa: E402
+from oracle import c_oracle  # noqa: E402
+from pnp_solver_test_amd import synth  # noqa: E402
+
+THREADS = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+K = synth.K_DEFAULT
+dev = torch.device("cuda:0")
+
+
+def oracle_threads(fn, uv, P):
+    n = len(uv)
+    bounds = [(i * n // THREADS, (i + 1) * n // THREADS) for i in range(THREADS)]
+    with ThreadPoolExecutor(THREADS) as ex:
+        parts = list(ex.map(lambda b: fn(uv[b[0]:b[1]], P, K), bounds))
+    return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+
+
+def rot_angle(A, B):
+    M = np.einsum("bij,bkj->bik", A, B)
+    skew = 0.5 * np.sqrt((M[:, 2, 1] - M[:, 1, 2]) ** 2 + (M[:, 0, 2] - M[:, 2, 0]) ** 2 + (M[:, 1, 0] - M[:, 0, 1]) ** 2)
+    return np.arctan2(skew, 0.5 * (np.trace(M, axis1=1, axis2=2) - 1.0))
+
+
+def stats(v):
+    v = v[np.isfinite(v)]
+    return dict(max=float(v.max()), p99=float(np.percentile(v, 99)), median=float(np.median(v)))
+
+
+def compare(out, ref, mask=None):
+    R = out["R"].cpu().numpy().astype(np.float64)
+    t = out["t"].cpu().numpy().astype(np.float64)
+    m = np.isfinite(ref["R"]).all(axis=(1, 2)) & np.isfinite(R).all(axis=(1, 2))
+    if mask is not None:
+        m &= mask
+    r = dict(problems=int(len(R)), compared=int(m.sum()), rotation_rad=stats(rot_angle(R[m], ref["R"][m])),
+             rel_translation=stats(np.linalg.norm(t[m] - ref["t"][m], axis=1) / np.linalg.norm(ref["t"][m], axis=1)),
+             max_abs_dR=float(np.abs(R[m] - ref["R"][m]).max()))
+    if "iters" in out:
+        r["iteration_mismatches"] = int((out["iters"].cpu().numpy() != ref["iters"]).sum())
+    return r
+
+
+report = dict(oracle="oracle/pnp_oracle.c on %d threads" % THREADS, cases={})
+cases = [("qeif_n6_b1m_quantised", 6, 1 << 20, True), ("qeif_n6_b1m_exact_pixels", 6, 1 << 20, False),
+         ("qeif_n68_b256k_quantised", 68, 1 << 18, True)]
+for tag, N, B, quant in cases:
+    P = synth.PATTERN6 if N == 6 else synth.face68()
+    uv, _ = synth.stress_batch(B, seed=42, pattern=P, K=K, is_quantized=quant, chunk=1 << 15)
+    for flavour, dt in (("f32", np.float32), ("f64", np.float64)):
+        Pd = P.astype(dt)
+        t0 = time.perf_counter()
+        ref = oracle_threads(c_oracle.qeif_batch, uv.astype(np.float64), Pd.astype(np.float64))
+        t_ref = time.perf_counter() - t0
+        out = pnp.solve_pnp_batch(torch.from_numpy(uv.astype(dt)).to(dev), torch.from_numpy(Pd).to(dev), K)
+        torch.cuda.synchronize()
+        r = compare(out, ref)
+        r["oracle_seconds"] = round(t_ref, 2)
+        report["cases"]["%s_%s" % (tag, flavour)] = r
+        print(tag, flavour, r, flush=True)
+    if N == 6 and quant:
+        for flavour, dt in (("f32", np.float32), ("f64", np.float64)):
+            Pd = P.astype(dt)
+            ref = oracle_threads(c_oracle.dlt_batch, uv.astype(np.float64), Pd.astype(np.float64))
+            out = pnp.solve_pnp_batch(torch.from_numpy(uv.astype(dt)).to(dev), torch.from_numpy(Pd).to(dev), K, method="dlt")
+            torch.cuda.synchronize()
+            clear = (ref["margins"][:, 0] > 1e-7) & (ref["margins"][:, 1] > 1e-7)
+            r = compare(out, ref, clear)
+            r["note"] = "compared where the oracle's sign-branch margins exceed 1e-7"
+            report["cases"]["dlt_n6_b1m_quantised_%s" % flavour] = r
+            print("dlt", flavour, r, flush=True)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(report, open(os.path.join(ROOT, "gpurun_out", "parity_report.json"), "w"), indent=1)

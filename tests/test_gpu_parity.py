@@ -1059,3 +1059,38 @@ def test_underdetermined_point_counts_do_not_fault(torch_dev, N):
         assert out["R"].shape == (300, 3, 3) and out["iters"].min() >= 1 and out["iters"].max() <= 14
     for method in ("dlt", "lm12"):
         assert solve_dev(uv, P, torch_dev, method=method)["t"].shape == (300, 3)
+
+
+# ---------------------------------------------------------------------------------------------
+# the whole headline batch against the oracle, problem by problem
+# ---------------------------------------------------------------------------------------------
+
+def test_every_problem_of_the_headline_batch_against_the_oracle(torch_dev):
+    """1,048,576 six-point problems (the bench workload, seed 42) and 262,144 68-point problems:
+    the C oracle solves every one of them on the host's threads; iteration counts must be equal
+    everywhere and the poses equal to one float32 output rounding."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    from pnp_solver_test_amd import synth
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+
+    def oracle(uv, P):
+        n = len(uv)
+        bounds = [(i * n // threads, (i + 1) * n // threads) for i in range(threads)]
+        with ThreadPoolExecutor(threads) as ex:
+            parts = list(ex.map(lambda b: c_oracle.qeif_batch(uv[b[0]:b[1]], P, K), bounds))
+        return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+
+    for N, B, P in ((6, 1 << 20, synth.PATTERN6), (68, 1 << 18, synth.face68())):
+        uv, _ = synth.stress_batch(B, seed=42, pattern=P, K=K, is_quantized=True, chunk=1 << 15)
+        P32 = P.astype(np.float32)
+        ref = oracle(uv.astype(np.float64), P32.astype(np.float64))
+        out = pnp.solve_pnp_batch(torch.from_numpy(uv).to(torch_dev), torch.from_numpy(P32).to(torch_dev), K)
+        torch.cuda.synchronize()
+        out = to_np(out)
+        assert np.array_equal(out["iters"], ref["iters"]), N
+        assert np.abs(out["R"].astype(np.float64) - ref["R"]).max() <= DR_TIGHT
+        assert rel_t(out["t"], ref["t"]).max() <= RELT_TIGHT
+        assert rot_angle(out["R"], ref["R"]).max() <= 2e-7
+        assert np.abs(out["rpy_deg"] - ref["rpy"]).max() <= 5e-4
