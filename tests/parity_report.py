@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repository root
 sys.path.insert(0, ROOT)
 import pnp_solver_test_amd as pnp  # noqa: E402
 from oracle import c_oracle  # noqa: E402
