@@ -1094,3 +1094,81 @@ def test_every_problem_of_the_headline_batch_against_the_oracle(torch_dev):
         assert rel_t(out["t"], ref["t"]).max() <= RELT_TIGHT
         assert rot_angle(out["R"], ref["R"]).max() <= 2e-7
         assert np.abs(out["rpy_deg"] - ref["rpy"]).max() <= 5e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# randomised sweep over the call space of the C ABI (device pointers): sizes, strides,
+# alignment, element types, forms, pattern layouts - every draw checked against the C oracle
+# ---------------------------------------------------------------------------------------------
+
+def test_randomised_call_space_against_oracle(torch_dev):
+    import torch
+    from pnp_solver_test_amd import synth
+    lib = _lib.load()
+    rng = np.random.default_rng(2024)
+    vp = ctypes.c_void_p
+    Kc = _lib.k_array(K)
+    checked = 0
+    for draw in range(48):
+        N = int(rng.choice([4, 6, 6, 7, 12, 15, 23, 68]))
+        B = int(rng.choice([1, 5, 64, 200, 257, 1000, 3000]))
+        f64 = bool(rng.integers(2))
+        own = bool(rng.integers(2))
+        pad = int(rng.choice([0, 0, 1, 5])) if own else 0           # extra elements between problems' patterns
+        shift = int(rng.choice([0, 0, 1, 3]))                        # misalignment of the arrays, in elements
+        method = str(rng.choice(["qeif", "qeif", "dlt"]))
+        form = int(rng.choice([_lib.QEIF_FORM_AUTO, _lib.QEIF_FORM_POINTS, _lib.QEIF_FORM_MOMENTS]))
+        lanes = int(rng.choice([0, 0, 0, 1, 8, 64])) if form != _lib.QEIF_FORM_MOMENTS else 0
+        dt, tdt = (np.float64, torch.float64) if f64 else (np.float32, torch.float32)
+        P = rng.uniform([-0.07, -0.05, -0.04], [0.07, 0.12, 0.02], (N, 3)).astype(dt)
+        uv, _ = synth.stress_batch(B, seed=1000 + draw, pattern=P.astype(np.float64), K=K, is_quantized=True)
+        uv = uv.astype(dt)
+        stride = 3 * N + pad if own else 0
+        # device buffers with a deliberate element offset, so that base pointers are not 16-byte aligned
+        d_uv = torch.zeros(B * 2 * N + shift, dtype=tdt, device=torch_dev)
+        d_uv[shift:] = torch.from_numpy(uv.reshape(-1)).to(torch_dev)
+        if own:
+            host_xyz = np.zeros((B, stride), dt)
+            host_xyz[:, :3 * N] = P.reshape(-1)
+            host_xyz[:, 3 * N:] = np.nan                              # padding must never be read as data
+        else:
+            host_xyz = P.reshape(1, -1)
+        d_xyz = torch.zeros(host_xyz.size + shift, dtype=tdt, device=torch_dev)
+        d_xyz[shift:] = torch.from_numpy(host_xyz.reshape(-1)).to(torch_dev)
+        R = torch.full((B, 9), float("nan"), dtype=tdt, device=torch_dev)
+        t = torch.full((B, 3), float("nan"), dtype=tdt, device=torch_dev)
+        res = torch.empty(B, dtype=tdt, device=torch_dev)
+        it = torch.zeros(B, dtype=torch.int32, device=torch_dev)
+        esz = 8 if f64 else 4
+        p_uv, p_xyz = vp(d_uv.data_ptr() + shift * esz), vp(d_xyz.data_ptr() + shift * esz)
+        lib.pnp_set_qeif_form(form)
+        lib.pnp_set_lanes_per_problem(lanes)
+        try:
+            if method == "qeif":
+                fn = lib.pnp_qeif_batch_f64 if f64 else lib.pnp_qeif_batch_f32
+                rc = fn(p_uv, p_xyz, stride, Kc, B, N, None, R.data_ptr(), t.data_ptr(), res.data_ptr(), it.data_ptr(),
+                        None, _lib.PTR_DEVICE, None)
+            else:
+                fn = lib.pnp_dlt_batch_f64 if f64 else lib.pnp_dlt_batch_f32
+                rc = fn(p_uv, p_xyz, stride, Kc, B, N, 3, R.data_ptr(), t.data_ptr(), res.data_ptr(), None,
+                        _lib.PTR_DEVICE, None)
+        finally:
+            lib.pnp_set_qeif_form(_lib.QEIF_FORM_AUTO)
+            lib.pnp_set_lanes_per_problem(0)
+        _lib.check(rc)
+        torch.cuda.synchronize()
+        Rn, tn = R.cpu().numpy().astype(np.float64).reshape(B, 3, 3), t.cpu().numpy().astype(np.float64)
+        what = (draw, N, B, f64, own, pad, shift, method, form, lanes)
+        if method == "qeif":
+            ref = c_oracle.qeif_batch(uv.astype(np.float64), P.astype(np.float64), K)
+            assert np.array_equal(it.cpu().numpy(), ref["iters"]), what
+            tol = 1e-9 if f64 else DR_TIGHT
+            assert np.abs(Rn - ref["R"]).max() <= tol, what
+            assert rel_t(tn, ref["t"]).max() <= (1e-9 if f64 else RELT_TIGHT), what
+        else:
+            ref = c_oracle.dlt_batch(uv.astype(np.float64), P.astype(np.float64), K)
+            clear = np.isfinite(ref["R"]).all(axis=(1, 2)) & (ref["margins"][:, :2].min(axis=1) > 1e-6)
+            if N >= 6 and clear.any():
+                assert np.abs(Rn - ref["R"])[clear].max() <= (1e-6 if f64 else 2e-6), what
+        checked += 1
+    assert checked == 48
