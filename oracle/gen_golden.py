@@ -95,7 +95,7 @@ def main():
     ap.add_argument('--ref', default='/root/reference/scripts')
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
     ap.add_argument('--n-stress', type=int, default=10000)
-    ap.add_argument('--only', default='', help='comma-separated section numbers (1-10); default all')
+    ap.add_argument('--only', default='', help='comma-separated section numbers (1-11); default all')
     args = ap.parse_args()
     out_dir = os.path.abspath(args.out)
     os.makedirs(out_dir, exist_ok=True)
@@ -393,6 +393,58 @@ def main():
         save('stress_epilogue.npz', avg_normalized=avg, max_normalized=mx, max_key=key, t_gt_est=t_gt_est,
              failed_sample_count=np.int64(failed), failed_sample_fit_error_count=np.int64(fit_failed),
              names=np.array(names))
+
+    # ---- 11. four-way (distance, roll, pitch, yaw) class cells and angle-filtered classes ----
+    if want(11):
+        import contextlib
+        import io
+        g = np.load(os.path.join(out_dir, 'stress_qeif_n6.npz'))
+        e = np.load(os.path.join(out_dir, 'stress_epilogue.npz'))
+        with contextlib.redirect_stdout(io.StringIO()):
+            cls = TTBX.get_classification_parameters(drpy_class_format='drpy_expand')
+        results = []
+        for i in range(len(g['t3'])):
+            dist_cm = g['t_gt'][i, 2] * 100.0
+            results.append({
+                'class': {'distance': TTBX.classify_drpy(cls, dist_cm, class_name='depth'),
+                          'roll': TTBX.classify_drpy(cls, g['roll_gt'][i], class_name='roll'),
+                          'pitch': TTBX.classify_drpy(cls, g['pitch_gt'][i], class_name='pitch'),
+                          'yaw': TTBX.classify_drpy(cls, g['yaw_gt'][i], class_name='yaw')},
+                't3_est': g['t3'][i], 'distance_GT': dist_cm * 0.01,
+                'roll_est': g['roll'][i], 'roll_GT': g['roll_gt'][i],
+                'pitch_est': g['pitch'][i], 'pitch_GT': g['pitch_gt'][i],
+                'yaw_est': g['yaw'][i], 'yaw_GT': g['yaw_gt'][i],
+                'LM_GT_error_average_normalize': e['avg_normalized'][i, 0]})
+        cells, d_l, r_l, p_l, y_l = TTBX.get_all_class_seperated_result(results)          # TEST_TOOLBOX.py:1233
+        specs = [('depth', 't3_est', 'distance_GT', 'cm', 100.0), ('roll', 'roll_est', 'roll_GT', 'deg.', 1.0),
+                 ('pitch', 'pitch_est', 'pitch_GT', 'deg.', 1.0), ('yaw', 'yaw_est', 'yaw_GT', 'deg.', 1.0),
+                 ('LM_GT_error_average_normalize', 'LM_GT_error_average_normalize', None, 'px_m', 1.0)]
+        fields = ['n_data', 'm_ratio', 'mean', 'stddev', 'max_dev', 'MAE_2_GT', 'MAE_2_mean']
+        arrs = {}
+        for name, est_key, gt_key, unit, scale in specs:                                   # :1240-1245
+            st = TTBX.get_drpy_statistic(cells, class_name=name, data_est_key=est_key, data_GT_key=gt_key,
+                                         unit=unit, unit_scale=scale)
+            A = np.full((len(d_l), len(r_l), len(p_l), len(y_l), len(fields)), np.nan)
+            for a, d in enumerate(d_l):
+                for b, r in enumerate(r_l):
+                    for c, pp in enumerate(p_l):
+                        for dd, y in enumerate(y_l):
+                            s_ = st.get(d, {}).get(r, {}).get(pp, {}).get(y)
+                            if s_:
+                                A[a, b, c, dd] = [s_['n_data'], s_['m_ratio']] + [s_['%s(%s)' % (k, unit)] for k in fields[2:]]
+            arrs['cells_' + name] = A
+        # distance classes restricted to small / large ground-truth angles (:959-970, :1174-1175)
+        for tag, fn in (('small', TTBX.approval_func_small_angle), ('large', TTBX.approval_func_large_angle)):
+            by = TTBX.get_classified_result(results, class_name='distance', include_all=False, approval_func=fn)
+            A = np.full((len(d_l), len(fields)), np.nan)
+            for a, d in enumerate(d_l):
+                s_ = TTBX.get_statistic_of_result(by.get(d, []), data_est_key='yaw_est', data_GT_key='yaw_GT',
+                                                  unit='deg.', unit_scale=1.0, verbose=False)
+                if s_:
+                    A[a] = [s_['n_data'], s_['m_ratio']] + [s_['%s(deg.)' % k] for k in fields[2:]]
+            arrs['yaw_by_distance_%s_angles' % tag] = A
+        save('stress_cells.npz', d_labels=np.array(d_l), r_labels=np.array(r_l), p_labels=np.array(p_l),
+             y_labels=np.array(y_l), fields=np.array(fields), **arrs)
 
     print('done in %.0f s; numpy %s' % (time.time() - t_start, np.__version__))
 

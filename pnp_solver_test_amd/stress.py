@@ -5,8 +5,9 @@ launch and ONE comparison launch - pose draws in the driver's order (:245-258), 
 pixel quantisation (PNP_SOLVER_LIB.py:4532-4557), solve_pnp on the six-landmark subset, the
 10 cm / 10 deg pass criteria (:374-377, TEST_TOOLBOX.py:55-62) and the landmark error sets of
 compare_result_and_generate_result_dict (TEST_TOOLBOX.py:312-343, :453-463) with the failure
-counters built on them (:408-415), ground-truth classes (TEST_TOOLBOX.py:133-247) and the
-per-class error statistics (TEST_TOOLBOX.py:892-937, :1173-1188).
+counters built on them (:408-415), ground-truth classes (TEST_TOOLBOX.py:133-247), the
+per-class error statistics (TEST_TOOLBOX.py:892-937, :1173-1188), their small-/large-angle
+restrictions (:959-970) and the four-way class-cell statistics (:975-1064, :1233-1245).
 
 landmark_noise_sweep(): scripts/LM_noise_test.py:141-175, :253-360 - yaw x noise-sigma grid of
 noisy landmark sets, all cells solved in one launch, yaw-error mean / stddev / MAE meshes.
@@ -36,21 +37,55 @@ def classify(values, class_name):
     return np.array(labels)[np.digitize(values, bins)]
 
 
-def error_statistics(est, gt, unit_scale=1.0):
-    """The reference's statistics of an estimate against ground truth
-    (TEST_TOOLBOX.get_statistic_of_result, :892-937)."""
+STAT_FIELDS = ("n_data", "m_ratio", "mean", "stddev", "max_dev", "MAE_2_GT", "MAE_2_mean")
+
+
+def error_statistics(est, gt=None, unit_scale=1.0):
+    """The reference's statistics of an estimate against ground truth, or of the value itself
+    when gt is None (TEST_TOOLBOX.get_statistic_of_result, :892-937)."""
     est = np.asarray(est, dtype=np.float64)
-    gt = np.asarray(gt, dtype=np.float64)
     n = est.shape[0]
     if n == 0:
         return None
-    err = est - gt
+    if gt is None:
+        err, ratio = est, est
+    else:
+        gt = np.asarray(gt, dtype=np.float64)
+        err, ratio = est - gt, est / gt
     mean = np.average(err)
-    return dict(n_data=n, m_ratio=np.average(est / gt), mean=mean * unit_scale,
+    return dict(n_data=n, m_ratio=np.average(ratio), mean=mean * unit_scale,
                 stddev=(np.sum((err - mean) ** 2) / n) ** 0.5 * unit_scale,
                 max_dev=np.max(np.abs(err - mean)) * unit_scale,
                 MAE_2_GT=np.sum(np.abs(err)) / n * unit_scale,
                 MAE_2_mean=np.sum(np.abs(err - mean)) / n * unit_scale)
+
+
+def small_angle_mask(roll_gt, pitch_gt, yaw_gt, angle_th=30.0):
+    """TEST_TOOLBOX.approval_func_small_angle (:959-967): every ground-truth angle within the
+    threshold; its complement is approval_func_large_angle (:969-970)."""
+    return (np.abs(roll_gt) <= angle_th) & (np.abs(pitch_gt) <= angle_th) & (np.abs(yaw_gt) <= angle_th)
+
+
+def class_cell_statistics(classes, est, gt=None, unit_scale=1.0):
+    """Statistics of one quantity in every (distance, roll, pitch, yaw) class cell
+    (TEST_TOOLBOX.get_all_class_seperated_result + get_drpy_statistic, :975-1064).
+    classes: dict of four label arrays as returned by random_stress.  Returns (labels, A):
+    labels = the four label lists in numeric order, A[d, r, p, y, :] = STAT_FIELDS of the cell,
+    NaN where a cell is empty."""
+    names = ("distance", "roll", "pitch", "yaw")
+    labels = [sorted(set(classes[k].tolist()), key=float) for k in names]
+    index = [np.array([lab.index(v) for v in classes[k].tolist()]) for k, lab in zip(names, labels)]
+    shape = tuple(len(lab) for lab in labels)
+    flat = np.ravel_multi_index(index, shape)
+    order = np.argsort(flat, kind="stable")                 # keeps sample order inside a cell, as the lists do
+    est = np.asarray(est, dtype=np.float64)
+    gt = None if gt is None else np.asarray(gt, dtype=np.float64)
+    A = np.full(shape + (len(STAT_FIELDS),), np.nan)
+    cuts = np.flatnonzero(np.diff(flat[order])) + 1
+    for idx in np.split(order, cuts):
+        st = error_statistics(est[idx], None if gt is None else gt[idx], unit_scale)
+        A[np.unravel_index(flat[idx[0]], shape)] = [st[k] for k in STAT_FIELDS]
+    return labels, A
 
 
 def random_stress(count, seed=42, pattern15=None, lm_rows=None, K=synth.K_DEFAULT, is_quantized=True,
@@ -60,8 +95,10 @@ def random_stress(count, seed=42, pattern15=None, lm_rows=None, K=synth.K_DEFAUL
     Returns a dict with the ground truth, the estimates, `passed` (count,4) = depth, roll, pitch,
     yaw within bounds, `pass_count`, the normalised landmark errors `lm_err_avg` / `lm_err_max` /
     `lm_err_key` (count,3) for observed-vs-truth, reprojection-vs-observed, reprojection-vs-truth,
-    `failed_sample_count`, `failed_sample_fit_error_count`, and `stats` = per distance class (and
-    "all") statistics of depth (cm), roll, pitch and yaw (deg) errors."""
+    `failed_sample_count`, `failed_sample_fit_error_count`, `stats` = per distance class (and
+    "all") statistics of depth (cm), roll, pitch and yaw (deg) errors, and `cell_labels`,
+    `cell_stats` = the same statistics (plus those of the normalised observed-vs-truth landmark
+    error) in every (distance, roll, pitch, yaw) class cell, see class_cell_statistics."""
     if pattern15 is None:
         pattern15, lm_rows = synth.PATTERN6, list(range(6))
     pattern15 = np.asarray(pattern15, dtype=np.float64)
@@ -87,6 +124,12 @@ def random_stress(count, seed=42, pattern15=None, lm_rows=None, K=synth.K_DEFAUL
                             roll=error_statistics(res["rpy_deg"][m, 0], roll[m]),
                             pitch=error_statistics(res["rpy_deg"][m, 2], pitch[m]),
                             yaw=error_statistics(res["rpy_deg"][m, 1], yaw[m]))
+    cell_stats = {}
+    for name, e_, g_, scale in (("depth", res["t3"], t[:, 2], 100.0), ("roll", res["rpy_deg"][:, 0], roll, 1.0),
+                                ("pitch", res["rpy_deg"][:, 2], pitch, 1.0), ("yaw", res["rpy_deg"][:, 1], yaw, 1.0),
+                                ("LM_GT_error_average_normalize", res["lm_err_avg"][:, 0], None, 1.0)):
+        cell_labels, cell_stats[name] = class_cell_statistics(classes, e_, g_, scale)     # TEST_TOOLBOX.py:1240-1245
+    res["cell_labels"], res["cell_stats"] = cell_labels, cell_stats
     return dict(roll_gt=roll, pitch_gt=pitch, yaw_gt=yaw, t_gt=t, uv=uv_all.detach().cpu().numpy(), classes=classes,
                 passed=passed, pass_count=passed.sum(axis=1), failed_sample_count=int(failed.sum()),
                 failed_sample_fit_error_count=int(fit_failed.sum()), stats=stats, **res)

@@ -610,6 +610,12 @@ def test_random_stress_driver_matches_reference_run(golden, torch_dev):
             assert mine["n_data"] == d["n_data"]
             for kk in ("mean", "stddev", "max_dev", "MAE_2_GT", "MAE_2_mean"):
                 assert abs(mine[kk] - d["%s(%s)" % (kk, unit)]) <= 2e-4, (label, q, kk)
+    c = golden("stress_cells")                          # four-way class cells of the reference toolbox
+    assert r["cell_labels"] == [c[k].tolist() for k in ("d_labels", "r_labels", "p_labels", "y_labels")]
+    for name in ("depth", "roll", "pitch", "yaw"):
+        A, ref_cells = r["cell_stats"][name], c["cells_" + name]
+        assert np.array_equal(A[..., 0], ref_cells[..., 0], equal_nan=True)            # n_data per cell
+        assert np.nanmax(np.abs(A[..., 2:] - ref_cells[..., 2:])) <= 5e-4, name        # float32 estimates
     big = stress.random_stress(1 << 18, seed=7, device=torch_dev)      # a quarter-million samples, two launches
     assert 0.97 < big["passed"].all(axis=1).mean() < 0.995
     assert big["stats"]["all"]["depth"]["n_data"] == 1 << 18

@@ -247,3 +247,28 @@ def test_header_is_plain_c(tmp_path):
                     str(src), "-L", libdir, "-lpnp_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
                     "-o", str(exe)], check=True)
     assert subprocess.run([str(exe)]).returncode == 0       # no device needed for these three calls
+
+
+def test_class_cell_statistics_against_reference_toolbox(golden):
+    """Four-way class cells and the angle-restricted distance classes, computed from the
+    reference run's own estimates, against the reference toolbox's numbers."""
+    from pnp_solver_test_amd import stress
+    g, e, c = golden("stress_qeif_n6"), golden("stress_epilogue"), golden("stress_cells")
+    dist_cm = g["t_gt"][:, 2] * 100.0
+    classes = {"distance": stress.classify(dist_cm, "depth"), "roll": stress.classify(g["roll_gt"], "roll"),
+               "pitch": stress.classify(g["pitch_gt"], "pitch"), "yaw": stress.classify(g["yaw_gt"], "yaw")}
+    for name, est, gt, scale in (("depth", g["t3"], dist_cm * 0.01, 100.0), ("roll", g["roll"], g["roll_gt"], 1.0),
+                                 ("pitch", g["pitch"], g["pitch_gt"], 1.0), ("yaw", g["yaw"], g["yaw_gt"], 1.0),
+                                 ("LM_GT_error_average_normalize", e["avg_normalized"][:, 0], None, 1.0)):
+        labels, A = stress.class_cell_statistics(classes, est, gt, scale)
+        assert labels == [c[k].tolist() for k in ("d_labels", "r_labels", "p_labels", "y_labels")]
+        ref = c["cells_" + name]
+        assert np.array_equal(np.isnan(A), np.isnan(ref))
+        assert np.nanmax(np.abs(A - ref)) <= 1e-9, name
+    small = stress.small_angle_mask(g["roll_gt"], g["pitch_gt"], g["yaw_gt"])
+    for tag, mask in (("small", small), ("large", ~small)):
+        ref = c["yaw_by_distance_%s_angles" % tag]
+        for a, label in enumerate(c["d_labels"].tolist()):
+            m = mask & (classes["distance"] == label)
+            st = stress.error_statistics(g["yaw"][m], g["yaw_gt"][m])
+            assert np.abs(np.array([st[k] for k in stress.STAT_FIELDS]) - ref[a]).max() <= 1e-9, (tag, label)
