@@ -95,7 +95,7 @@ def main():
     ap.add_argument('--ref', default='/root/reference/scripts')
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
     ap.add_argument('--n-stress', type=int, default=10000)
-    ap.add_argument('--only', default='', help='comma-separated section numbers (1-11); default all')
+    ap.add_argument('--only', default='', help='comma-separated section numbers (1-12); default all')
     args = ap.parse_args()
     out_dir = os.path.abspath(args.out)
     os.makedirs(out_dir, exist_ok=True)
@@ -445,6 +445,64 @@ def main():
             arrs['yaw_by_distance_%s_angles' % tag] = A
         save('stress_cells.npz', d_labels=np.array(d_l), r_labels=np.array(r_l), p_labels=np.array(p_l),
              y_labels=np.array(y_l), fields=np.array(fields), **arrs)
+
+    # ---- 12. face-variation driver: perturbed generator patterns, nominal solver pattern -------
+    if want(12):
+        import contextlib
+        import heapq
+        import io
+        sink = io.StringIO()
+        for tag, n, random_pose in (('fixed_pose', 2000, False), ('random_pose', 600, True)):
+            rng = np.random.default_rng(42)
+            with contextlib.redirect_stdout(sink):
+                gt_solver = PNPS.PNP_SOLVER(K, [alex], pattern_scale_list=[1.0], verbose=False)
+                est_solver = PNPS.PNP_SOLVER(K, [alex], pattern_scale_list=[1.0], verbose=False)
+            pert = np.zeros((n, 15, 3))
+            poses = np.zeros((n, 6))                      # roll, pitch, yaw, t
+            uv15 = np.zeros((n, 15, 2))
+            abs_err = np.zeros((n, 4))
+            res = []
+            heaps = {k: [] for k in ('depth', 'roll', 'pitch', 'yaw')}
+            for i in range(n):
+                with contextlib.redirect_stdout(sink):
+                    if random_pose:                                           # face_variation_test.py:295-308
+                        roll, pitch, yaw, t = draw_stress_pose(rng)
+                    else:                                                     # :310-323
+                        roll = pitch = yaw = 0.0
+                        t = np.array([[0.0], [0.0], [1.0]])
+                    new_dict = {k: list(v) for k, v in alex.items()}
+                    M = rng.multivariate_normal(np.zeros((3,)), np.eye(3), 14)   # :351
+                    unit = gt_solver.unit_vec(M.reshape((42,)))
+                    PT = 0.02 * unit.reshape((3, 14))                          # :359
+                    pdict, j = {}, 0
+                    for k in new_dict:                                        # :365-371
+                        if k == 'eye_c_51':
+                            pdict[k] = np.zeros((3, 1))
+                        else:
+                            pdict[k] = PT[:, j:j + 1]
+                            new_dict[k] = list(np.array(new_dict[k]).reshape((3, 1)) + pdict[k])
+                            j += 1
+                    gt_solver.update_the_selected_golden_pattern(0, new_dict, 1.0)
+                    R_gt = gt_solver.get_rotation_matrix_from_Euler(roll, yaw, pitch, is_degree=True)
+                    gt_solver.set_golden_pattern_id(0)
+                    img = gt_solver.perspective_projection_golden_landmarks(R_gt, t, is_quantized=True)
+                    out = est_solver.solve_pnp(img)
+                sink.seek(0)
+                sink.truncate(0)
+                dist_cm = t[2, 0] * 100.0
+                abs_err[i] = [abs(out[2] - dist_cm * 0.01), abs(out[3] - roll), abs(out[5] - pitch), abs(out[4] - yaw)]
+                for c, q in enumerate(heaps):                                 # :517-520
+                    heapq.heappush(heaps[q], (-abs_err[i, c], i))
+                pert[i] = np.array([pdict[k][:, 0] for k in keys15])
+                poses[i] = [roll, pitch, yaw, t[0, 0], t[1, 0], t[2, 0]]
+                uv15[i] = dict_to_uv(img, keys15)
+                res.append(out)
+            n_top = int(n * 0.1)                                              # :640-641
+            tops = {}
+            for q in heaps:                                                   # :649-657
+                tops['top_idx_' + q] = np.array([heapq.heappop(heaps[q])[1] for _ in range(n_top)], dtype=np.int64)
+            save('face_variation_%s.npz' % tag, seed=np.int64(42), keys15=np.array(keys15), perturbation=pert,
+                 poses=poses, uv15=uv15.astype(np.float32), abs_err=abs_err, **tops, **pack(res))
 
     print('done in %.0f s; numpy %s' % (time.time() - t_start, np.__version__))
 

@@ -9,6 +9,12 @@ counters built on them (:408-415), ground-truth classes (TEST_TOOLBOX.py:133-247
 per-class error statistics (TEST_TOOLBOX.py:892-937, :1173-1188), their small-/large-angle
 restrictions (:959-970) and the four-way class-cell statistics (:975-1064, :1233-1245).
 
+face_variation(): scripts/face_variation_test.py:275-520, :640-735 - the generator's pattern is
+perturbed per sample (unit-norm direction over 14 of the 15 landmarks, 2 cm radius) while the
+solver keeps the nominal pattern; projection with one pattern per sample, solve and comparison
+are three launches; the top decile of each error is then analysed for the most displaced
+landmark and the dominant perturbation directions (SVD).
+
 landmark_noise_sweep(): scripts/LM_noise_test.py:141-175, :253-360 - yaw x noise-sigma grid of
 noisy landmark sets, all cells solved in one launch, yaw-error mean / stddev / MAE meshes.
 
@@ -159,3 +165,71 @@ def landmark_noise_sweep(yaw_list, sigma_list, noise, pattern15, lm_rows, K=synt
     err = yaw_est - yaw_list[:, None, None]
     return dict(yaw_est=yaw_est, uv_clean=clean, mesh_mean=err.mean(axis=2), mesh_std=err.std(axis=2),
                 mesh_mae=np.abs(err).mean(axis=2))
+
+
+def draw_pattern_perturbations(rng, count, n_points=15, fixed_row=0, radius=0.02, random_pose=False):
+    """The face-variation driver's draws, sample by sample in its order
+    (face_variation_test.py:295-308, :351-371): optionally a random-stress pose, then a
+    (n_points-1, 3) standard-normal matrix, flattened, normalised to unit length
+    (PNP_SOLVER.unit_vec, PNP_SOLVER_LIB.py:4666-4675), scaled by `radius` and read back as
+    a (3, n_points-1) matrix whose column j displaces the j-th landmark other than `fixed_row`.
+    Returns (roll, pitch, yaw, t (count,3), perturbation (count, n_points, 3))."""
+    m = n_points - 1
+    roll, pitch, yaw = np.zeros(count), np.zeros(count), np.zeros(count)
+    t = np.tile(np.array([0.0, 0.0, 1.0]), (count, 1))                      # :310-323
+    pert = np.zeros((count, n_points, 3))
+    free = [i for i in range(n_points) if i != fixed_row]
+    for i in range(count):
+        if random_pose:
+            r_, p_, y_, t_ = synth.sample_stress_poses(rng, 1)
+            roll[i], pitch[i], yaw[i], t[i] = r_[0], p_[0], y_[0], t_[0]
+        flat = rng.multivariate_normal(np.zeros(3), np.eye(3), m).reshape(3 * m)
+        norm = np.linalg.norm(flat)
+        unit = flat * (1.0e7 if abs(norm) <= 1e-7 else 1.0 / norm)
+        pert[i, free, :] = (radius * unit.reshape(3, m)).T
+    return roll, pitch, yaw, t, pert
+
+
+def perturbation_analysis(abs_err, perturbation, top_ratio=0.1, k_top_direction=5):
+    """Top-decile analysis of one error quantity (face_variation_test.py:640-657 and
+    get_most_fragile_point_and_perturbation_direction, :662-735): the samples with the largest
+    absolute error (ties in sample order, as the driver's heap pops them), how often each
+    landmark carried the largest displacement among them, and the leading right singular
+    vectors of their stacked perturbations.  The function in the reference sits in a script that
+    cannot be imported, so this restatement has no reference-generated fixture behind it."""
+    abs_err = np.asarray(abs_err, dtype=np.float64)
+    n_top = int(len(abs_err) * top_ratio)
+    order = np.lexsort((np.arange(len(abs_err)), -abs_err))[:n_top]
+    top = perturbation[order]                                               # (n_top, M, 3)
+    norms = np.linalg.norm(top, axis=2)
+    counts = np.bincount(np.argmax(norms, axis=1), minlength=perturbation.shape[1])
+    _, sv, vh = np.linalg.svd(top.reshape(n_top, -1))
+    k = min(k_top_direction, vh.shape[0])
+    return dict(top_idx=order, top_val=abs_err[order], fragile_point_count=counts,
+                top_directions=vh[:k].reshape(k, perturbation.shape[1], 3), top_singular_values=sv[:k],
+                value_max=float(abs_err[order[0]]) if n_top else float("nan"),
+                top_value_mean=float(abs_err[order].mean()) if n_top else float("nan"))
+
+
+def face_variation(count, seed=42, pattern15=None, fixed_row=0, lm_rows=None, K=synth.K_DEFAULT, is_quantized=True,
+                   random_pose=False, radius=0.02, device="cuda:0", error_bound=(10.0, 10.0, 10.0, 10.0)):
+    """Run `count` face-variation samples: landmarks generated from a per-sample perturbed copy of
+    pattern15 (all rows except fixed_row displaced), solved against the nominal rows lm_rows.
+    Returns ground truth, perturbations, pixels, estimates, the comparison epilogue's outputs,
+    abs_err (count,4) = depth [m], roll, pitch, yaw [deg], and `analysis` = perturbation_analysis
+    per quantity."""
+    pattern15 = np.asarray(pattern15, dtype=np.float64)
+    rng = np.random.default_rng(seed)
+    roll, pitch, yaw, t, pert = draw_pattern_perturbations(rng, count, pattern15.shape[0], fixed_row, radius, random_pose)
+    own = pattern15[None, :, :] + pert                                      # the generator's pattern, per sample
+    uv_all = _batch.project_batch(roll, yaw, pitch, t, own, K, 1.0 if is_quantized else 0.0, device=device)
+    out = _batch.solve_pnp_batch(uv_all[:, lm_rows, :].contiguous(), pattern15[lm_rows].astype(np.float32), K)
+    cmp_ = _batch.compare_batch(out["R"], out["t"], np.stack([roll, yaw, pitch], axis=1), t[:, 2] * 100.0,
+                                pattern15, K, uv_obs=uv_all, bound=error_bound)
+    res = {k: v.detach().cpu().numpy() for k, v in out.items()}
+    res.update({k: v.detach().cpu().numpy() for k, v in cmp_.items()})
+    abs_err = np.abs(np.stack([res["t3"].astype(np.float64) - t[:, 2], res["rpy_deg"][:, 0] - roll,
+                               res["rpy_deg"][:, 2] - pitch, res["rpy_deg"][:, 1] - yaw], axis=1))
+    analysis = {q: perturbation_analysis(abs_err[:, c], pert) for c, q in enumerate(("depth", "roll", "pitch", "yaw"))}
+    return dict(roll_gt=roll, pitch_gt=pitch, yaw_gt=yaw, t_gt=t, perturbation=pert, uv=uv_all.detach().cpu().numpy(),
+                abs_err=abs_err, analysis=analysis, **res)

@@ -272,3 +272,25 @@ def test_class_cell_statistics_against_reference_toolbox(golden):
             m = mask & (classes["distance"] == label)
             st = stress.error_statistics(g["yaw"][m], g["yaw_gt"][m])
             assert np.abs(np.array([st[k] for k in stress.STAT_FIELDS]) - ref[a]).max() <= 1e-9, (tag, label)
+
+
+@pytest.mark.parametrize("tag,random_pose", [("fixed_pose", False), ("random_pose", True)])
+def test_face_variation_draws_match_reference_run(golden, tag, random_pose):
+    """Pose and pattern-perturbation draws of the face-variation driver, seed 42, against what the
+    reference's generator produced; the top-decile ordering against its heap pops."""
+    from pnp_solver_test_amd import stress
+    g = golden("face_variation_" + tag)
+    n = len(g["perturbation"])
+    fixed = [str(k) for k in g["keys15"]].index("eye_c_51")
+    roll, pitch, yaw, t, pert = stress.draw_pattern_perturbations(np.random.default_rng(42), n, 15, fixed, 0.02,
+                                                                  random_pose)
+    assert np.array_equal(pert, g["perturbation"])
+    assert np.array_equal(np.column_stack([roll, pitch, yaw, t]), g["poses"])
+    assert np.allclose(np.linalg.norm(pert.reshape(n, -1), axis=1), 0.02, atol=1e-15)
+    for c, q in enumerate(("depth", "roll", "pitch", "yaw")):
+        a = stress.perturbation_analysis(g["abs_err"][:, c], pert)
+        assert np.array_equal(a["top_idx"], g["top_idx_" + q])
+        assert a["fragile_point_count"].sum() == n // 10 and a["fragile_point_count"][fixed] == 0
+        assert np.all(np.diff(a["top_singular_values"]) <= 0)
+        assert np.allclose(np.linalg.norm(a["top_directions"].reshape(5, -1), axis=1), 1.0)
+        assert a["value_max"] == g["abs_err"][:, c].max()
