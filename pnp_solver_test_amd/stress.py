@@ -179,14 +179,17 @@ def draw_pattern_perturbations(rng, count, n_points=15, fixed_row=0, radius=0.02
     t = np.tile(np.array([0.0, 0.0, 1.0]), (count, 1))                      # :310-323
     pert = np.zeros((count, n_points, 3))
     free = [i for i in range(n_points) if i != fixed_row]
-    for i in range(count):
-        if random_pose:
+    if random_pose:  # pose and perturbation draws interleave: one sample at a time, as the driver does
+        flat = np.empty((count, 3 * m))
+        for i in range(count):
             r_, p_, y_, t_ = synth.sample_stress_poses(rng, 1)
             roll[i], pitch[i], yaw[i], t[i] = r_[0], p_[0], y_[0], t_[0]
-        flat = rng.multivariate_normal(np.zeros(3), np.eye(3), m).reshape(3 * m)
-        norm = np.linalg.norm(flat)
-        unit = flat * (1.0e7 if abs(norm) <= 1e-7 else 1.0 / norm)
-        pert[i, free, :] = (radius * unit.reshape(3, m)).T
+            flat[i] = rng.multivariate_normal(np.zeros(3), np.eye(3), m).reshape(3 * m)
+    else:            # only the perturbations are drawn: one call yields the same stream
+        flat = rng.multivariate_normal(np.zeros(3), np.eye(3), (count, m)).reshape(count, 3 * m)
+    norm = np.linalg.norm(flat, axis=1)
+    unit = flat * np.where(np.abs(norm) <= 1e-7, 1.0e7, 1.0 / np.maximum(norm, 1e-300))[:, None]
+    pert[:, free, :] = np.transpose(radius * unit.reshape(count, 3, m), (0, 2, 1))
     return roll, pitch, yaw, t, pert
 
 
