@@ -187,7 +187,7 @@ def draw_pattern_perturbations(rng, count, n_points=15, fixed_row=0, radius=0.02
             flat[i] = rng.multivariate_normal(np.zeros(3), np.eye(3), m).reshape(3 * m)
     else:            # only the perturbations are drawn: one call yields the same stream
         flat = rng.multivariate_normal(np.zeros(3), np.eye(3), (count, m)).reshape(count, 3 * m)
-    norm = np.linalg.norm(flat, axis=1)
+    norm = np.array([np.linalg.norm(f) for f in flat])      # the driver's 1-D norm (a dot product), row by row
     unit = flat * np.where(np.abs(norm) <= 1e-7, 1.0e7, 1.0 / np.maximum(norm, 1e-300))[:, None]
     pert[:, free, :] = np.transpose(radius * unit.reshape(count, 3, m), (0, 2, 1))
     return roll, pitch, yaw, t, pert
