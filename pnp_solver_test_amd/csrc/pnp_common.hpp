@@ -26,6 +26,10 @@ struct Mat3 {  // row-major 3x3, passed to kernels by value
     double m[9];
 };
 
+struct PassBounds {  // pass criteria of the comparison epilogue: depth [cm], roll, pitch, yaw [deg]
+    double v[4];
+};
+
 struct QeifParams {
     double q_inv, r_quat, r_delta, omega0, rel_tol, res_old0;
     int max_it;

@@ -543,9 +543,10 @@ int compare_impl(const T *R_est, const T *t_est, const T *uv_obs, const double *
     const int64_t nblk = (B + kBlock - 1) / kBlock;
     if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
     const dim3 grid(static_cast<unsigned>(nblk));
-    pnp::Mat3 Km, bd;
+    pnp::Mat3 Km;
+    pnp::PassBounds bd;
     for (int i = 0; i < 9; ++i) Km.m[i] = K[i];
-    for (int i = 0; i < 9; ++i) bd.m[i] = (i < 4) ? (bound ? bound[i] : 10.0) : 0.0;
+    for (int i = 0; i < 4; ++i) bd.v[i] = bound ? bound[i] : 10.0;
     if (ptr_kind == PNP_PTR_DEVICE) {
         hipLaunchKernelGGL((pnp::compare_kernel<T>), grid, dim3(kBlock), 0, s, R_est, t_est, uv_obs, rpy_gt_deg,
                            distance_gt_cm, xyz, Km, B, M, bd, normalize, drpy_err, pass_mask, lm_err, lm_key);

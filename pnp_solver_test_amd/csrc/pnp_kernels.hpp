@@ -513,7 +513,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void compare_kernel(
     const T *__restrict__ R_est, const T *__restrict__ t_est, const T *__restrict__ uv_obs,
     const double *__restrict__ rpy_gt_deg, const double *__restrict__ distance_gt_cm,
-    const double *__restrict__ xyz, Mat3 Kmat, int64_t B, int M, Mat3 bound, int normalize,
+    const double *__restrict__ xyz, Mat3 Kmat, int64_t B, int M, PassBounds bound, int normalize,
     T *__restrict__ drpy_err, int32_t *__restrict__ pass_mask, T *__restrict__ lm_err,
     int32_t *__restrict__ lm_key)
 {
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(kBlock) void compare_kernel(
     int mask = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (fabs(err[k]) < bound.m[k]) mask |= 1 << k;
+        if (fabs(err[k]) < bound.v[k]) mask |= 1 << k;
         if (drpy_err) drpy_err[b * 4 + k] = static_cast<T>(err[k]);
     }
     if (pass_mask) pass_mask[b] = mask;
