@@ -13,6 +13,7 @@
 
 #include "pnp_hip.h"
 #include <algorithm>
+#include <cstring>
 
 #include "pnp_kernels.hpp"
 
@@ -59,7 +60,12 @@ struct Staging {
     std::mutex mu;
     void *buf = nullptr;
     size_t cap = 0;
+    void *pinned = nullptr;  // kSmallCall bytes of page-locked host memory, mirror of buf's first bytes
 };
+
+// Host-pointer calls whose arrays fit this many bytes go through the pinned mirror: one copy in
+// and one copy out instead of one per array (each copy from pageable memory costs ~10 us).
+constexpr size_t kSmallCall = 256 * 1024;
 Staging g_staging[kMaxDevices];
 
 // Grow-only device buffer of the current device; caller holds st.mu.
@@ -329,6 +335,7 @@ int with_host_staging(hipStream_t s, int64_t B, int32_t N, size_t xyz_elems, con
     SolveIO<T> d;
     T *d_uv = c.take<T>(nB * 2 * N);
     T *d_xyz = c.take<T>(xyz_elems);
+    const size_t in_bytes = c.off;
     d.uv = d_uv;
     d.xyz = d_xyz;
     d.R = c.take<T>(nB * 9);
@@ -337,6 +344,30 @@ int with_host_staging(hipStream_t s, int64_t B, int32_t N, size_t xyz_elems, con
     d.rpy = h.rpy ? c.take<T>(nB * 3) : nullptr;
     d.iters = h.iters ? c.take<int32_t>(nB) : nullptr;
     d.pid = h.pid ? c.take<int32_t>(nB) : nullptr;
+    const size_t all_bytes = c.off;
+
+    if (all_bytes <= kSmallCall) {
+        // small call: gather the inputs in the pinned mirror, one copy each way
+        if (!st.pinned) HIP_TRY(hipHostMalloc(&st.pinned, kSmallCall, hipHostMallocDefault));
+        char *m = static_cast<char *>(st.pinned);
+        auto mirror = [&](const void *dev_ptr) { return m + (static_cast<const char *>(dev_ptr) - static_cast<char *>(st.buf)); };
+        std::memcpy(mirror(d_uv), h.uv, nB * 2 * N * sizeof(T));
+        std::memcpy(mirror(d_xyz), h.xyz, xyz_elems * sizeof(T));
+        HIP_TRY(hipMemcpyAsync(st.buf, m, in_bytes, hipMemcpyHostToDevice, s));
+        rc = run(d);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(m + in_bytes, static_cast<char *>(st.buf) + in_bytes, all_bytes - in_bytes,
+                               hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        std::memcpy(h.R, mirror(d.R), nB * 9 * sizeof(T));
+        std::memcpy(h.t, mirror(d.t), nB * 3 * sizeof(T));
+        if (h.res) std::memcpy(h.res, mirror(d.res), nB * sizeof(T));
+        if (h.rpy) std::memcpy(h.rpy, mirror(d.rpy), nB * 3 * sizeof(T));
+        if (h.iters) std::memcpy(h.iters, mirror(d.iters), nB * sizeof(int32_t));
+        if (h.pid) std::memcpy(h.pid, mirror(d.pid), nB * sizeof(int32_t));
+        return PNP_OK;
+    }
+
     HIP_TRY(hipMemcpyAsync(d_uv, h.uv, nB * 2 * N * sizeof(T), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_xyz, h.xyz, xyz_elems * sizeof(T), hipMemcpyHostToDevice, s));
     rc = run(d);
