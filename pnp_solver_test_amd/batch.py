@@ -234,19 +234,32 @@ def shard_bounds(total: int, rank: int, world_size: int):
 
 
 def gather_results(local: dict, group=None) -> dict:
-    """Optional collective after a sharded solve: all-gather every rank's result arrays
-    (torch tensors of equal per-rank length) in rank order.  Uses torch.distributed, i.e.
-    RCCL over xGMI for HIP tensors and gloo for CPU tensors."""
+    """Optional collective after a sharded solve: all-gather every rank's result arrays (torch
+    tensors) in rank order.  Slices may differ in length (shard_bounds hands out sizes that
+    differ by one): shorter ones are padded for the collective and trimmed afterwards.  Uses
+    torch.distributed, i.e. RCCL over xGMI for HIP tensors and gloo for CPU tensors."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
+    first = next(iter(local.values()))
+    n_local = torch.tensor([first.shape[0]], dtype=torch.int64, device=first.device)
+    counts = torch.empty(world, dtype=torch.int64, device=first.device)
+    dist.all_gather_into_tensor(counts, n_local, group=group)
+    counts = counts.tolist()
+    n_max = max(counts)
     out = {}
     for key, val in local.items():
         val = val.contiguous()
-        buf = torch.empty((world * val.shape[0],) + tuple(val.shape[1:]), dtype=val.dtype, device=val.device)
+        if val.shape[0] < n_max:
+            pad = torch.zeros((n_max - val.shape[0],) + tuple(val.shape[1:]), dtype=val.dtype, device=val.device)
+            val = torch.cat([val, pad], dim=0)
+        buf = torch.empty((world * n_max,) + tuple(val.shape[1:]), dtype=val.dtype, device=val.device)
         dist.all_gather_into_tensor(buf, val, group=group)
-        out[key] = buf
+        if min(counts) == n_max:
+            out[key] = buf
+        else:
+            out[key] = torch.cat([buf[r * n_max:r * n_max + counts[r]] for r in range(world)], dim=0)
     return out
 
 

@@ -47,9 +47,10 @@ def _worker(rank, world, port, total, out_path):
 
 
 @pytest.mark.timeout(120)
-def test_two_rank_slices_and_gather(tmp_path):
+@pytest.mark.parametrize("total", [2000, 1999])          # equal slices, and slices that differ by one
+def test_two_rank_slices_and_gather(tmp_path, total):
     from oracle import c_oracle, pnp_oracle as po
-    total, world = 2000, 2
+    world = 2
     out_path = str(tmp_path / "gathered.npz")
     mp.spawn(_worker, args=(world, _free_port(), total, out_path), nprocs=world, join=True)
     got = np.load(out_path)
