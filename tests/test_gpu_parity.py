@@ -1207,3 +1207,36 @@ def test_face_variation_driver_matches_reference_run(golden, torch_dev, tag, ran
     assert np.isfinite(r["R"]).all()
     assert (r["passed"] == ref_pass)[same_px].mean() >= 0.9995
     assert r["lm_err_avg"][:, 0].min() > 0.0                            # observed landmarks are off the nominal projection
+
+
+# ---------------------------------------------------------------------------------------------
+# concurrent callers
+# ---------------------------------------------------------------------------------------------
+
+def test_concurrent_host_pointer_callers(golden, torch_dev):
+    """Four host threads call the host-pointer path at once (ctypes drops the interpreter lock
+    during the call): the per-device staging buffers serialise them, every caller gets its own
+    results, and an argument error in one thread leaves the others' error text alone."""
+    from concurrent.futures import ThreadPoolExecutor
+    g, uv = stress_uv6(golden)
+    sizes = [1, 7, 300, 2048, 9000]
+    expect = {B: pnp.solve_pnp_batch(uv[:B], P6f, K) for B in sizes}
+    expect_d = {B: pnp.solve_pnp_batch(uv[:B], P6f, K, method="dlt") for B in sizes}
+
+    def worker(seed):
+        rng = np.random.default_rng(seed)
+        bad = 0
+        for _ in range(40):
+            B = int(rng.choice(sizes))
+            if rng.integers(2):
+                out, ref = pnp.solve_pnp_batch(uv[:B], P6f, K), expect[B]
+            else:
+                out, ref = pnp.solve_pnp_batch(uv[:B], P6f, K, method="dlt"), expect_d[B]
+            bad += not all(np.array_equal(out[k], ref[k], equal_nan=True) for k in ref)
+            if rng.integers(4) == 0:
+                with pytest.raises(_lib.PnpError, match="outside"):
+                    pnp.solve_pnp_batch(np.zeros((2, 600, 2), np.float32), np.zeros((600, 3), np.float32), K)
+        return bad
+
+    with ThreadPoolExecutor(4) as ex:
+        assert sum(ex.map(worker, range(4))) == 0
