@@ -295,23 +295,26 @@ def main():
         if world == 1 and not args.no_other_configs:
             other = {}
             n_small = max(5, min(50, args.steps // 2))
+            # every variant gets its own spin-up: the host work between two variants leaves the GPU
+            # idle long enough for its clock to drop, and the first ~20 ms of launches run slow
+            n_spin = 100
             P6 = torch.from_numpy(synth.PATTERN6.astype(np.float32)).to(dev)
-            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, P6, K, want_rpy=False), n_small, 3)
+            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, P6, K, want_rpy=False), n_small, n_spin)
             other["qeif_n6_shared_pattern"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4),
                                                    bytes_per_solve=8 * N_POINTS + 48)
             p5 = pnp.make_params(max_it=5, rel_tol=0.0)
-            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, xyz, K, params=p5, want_rpy=False), n_small, 3)
+            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, xyz, K, params=p5, want_rpy=False), n_small, n_spin)
             other["qeif_n6_fixed_5_iterations"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4))
-            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, xyz, K, want_rpy=True), n_small, 3)
+            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, xyz, K, want_rpy=True), n_small, n_spin)
             other["qeif_n6_with_euler_output"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4))
-            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, xyz, K, method="dlt", want_rpy=False), n_small, 3)
+            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, xyz, K, method="dlt", want_rpy=False), n_small, n_spin)
             gbs = B * bytes_per_solve / (ms * 1e-3) / 1e9
             other["configs[1]_dlt_n6_b1m"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4),
                                                   achieved_GBps=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4),
                                                   valu_fp64_TFLOPs=round(B * dlt_flops(6) / (ms * 1e-3) / 1e12, 2))
             B_lm = 1 << 18
             ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv[:B_lm], xyz[:B_lm], K, method="lm12", want_rpy=False),
-                               5, 1)
+                               10, 25)
             other["lm12_n6_b256k (secondary solver)"] = dict(solves_per_s=round(B_lm / ms * 1e3, 1), kernel_ms=round(ms, 4))
             B68 = 1 << 18
             P68 = synth.face68()
@@ -323,7 +326,7 @@ def main():
             it68 = float(o68["iters"].float().mean().item())
             own68 = P68d[None].expand(B68, 68, 3).contiguous()
             for tag, xyz68, nbytes in (("shared_pattern", P68d, 8 * 68 + 48), ("per_problem_pattern", own68, 20 * 68 + 48)):
-                ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv68, xyz68, K, want_rpy=False), n_small, 3)
+                ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv68, xyz68, K, want_rpy=False), n_small, n_spin)
                 gbs = B68 * nbytes / (ms * 1e-3) / 1e9
                 other["configs[3]_qeif_n68_b256k_" + tag] = dict(
                     solves_per_s=round(B68 / ms * 1e3, 1), kernel_ms=round(ms, 4), mean_iterations=round(it68, 3),
@@ -331,7 +334,7 @@ def main():
                     form="moments" if lib.pnp_get_qeif_form(B68, 68) == pnp._lib.QEIF_FORM_MOMENTS else "points",
                     valu_fp64_TFLOPs=round(B68 * qeif_moment_flops(68, it68) / (ms * 1e-3) / 1e12, 2))
             lib.pnp_set_qeif_form(pnp._lib.QEIF_FORM_POINTS)        # the point-by-point form, for comparison
-            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv68, P68d, K, want_rpy=False), 5, 2)
+            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv68, P68d, K, want_rpy=False), 10, 25)
             lib.pnp_set_qeif_form(pnp._lib.QEIF_FORM_AUTO)
             other["configs[3]_qeif_n68_b256k_shared_pattern_point_form"] = dict(
                 solves_per_s=round(B68 / ms * 1e3, 1), kernel_ms=round(ms, 4),
@@ -339,11 +342,11 @@ def main():
                 valu_fp64_TFLOPs=round(B68 * qeif_flops(68, it68) / (ms * 1e-3) / 1e12, 2))
             del own68
             uv64, xyz64 = uv.double(), xyz.double()          # the reference's own dtype end to end
-            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv64, xyz64, K, want_rpy=False), n_small, 3)
+            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv64, xyz64, K, want_rpy=False), n_small, n_spin)
             other["qeif_n6_b1m_float64_io"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4),
                                                    bytes_per_solve=2 * bytes_per_solve)
             ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv64, xyz64, K, method="dlt", want_rpy=False),
-                               n_small, 3)
+                               n_small, n_spin)
             gbs = B * (2 * bytes_per_solve) / (ms * 1e-3) / 1e9
             other["dlt_n6_b1m_float64_io"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4),
                                                   achieved_GBps=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4))
