@@ -368,15 +368,16 @@ __global__ __launch_bounds__(kSolveBlock<T>, PNP_QEIF_WAVES) void qeif_moment_ke
         return ss;
     };
     QeifState st;
-    qeif_init(st, p);
+    qeif_init(st, p, 1.0);
+    const QeifRule rule(p);
     const double n = static_cast<double>(N);
     while (st.k < p.max_it) {
-        if (qeif_moment_iterate(st, M, n, p, exact_ss)) break;
+        if (qeif_moment_iterate(st, M, n, p, rule, exact_ss)) break;
     }
     double R[9], t[3];
     qeif_finish(st, R, t);
     store_pose(problem, R, t, R_out, t_out);
-    if (res_out) res_out[problem] = static_cast<T>(st.res);
+    if (res_out) res_out[problem] = static_cast<T>(qeif_residual(st, 1.0));
     if (iters_out) iters_out[problem] = st.k;
     if (rpy_out) store_rpy(problem, R, rpy_out);
 }

@@ -18,6 +18,7 @@ namespace pnp {
 //   s~ = c * s with  p^T Q1 = [s0 s1 s2 s3], p^T Q2 = [-s3 -s2 s1 s0], p^T Q3 = [s2 -s3 -s0 s1]
 //        (the three 3x4 Jacobians d(phi_j)/dq share these four products of the point with 2q)
 //   c * P phi_j = (p^T Q_j) . q / 2           (phi_j is a quadratic form in q)
+//   ncd1 = -c * delta1, ncd2 = -c * delta2
 //   u~ = c (p^T Q1 - bx p^T Q3), v~ = c (p^T Q2 - by p^T Q3): rows H_x = [u, 1, 0], H_y = [v, 0, 1]
 //   r~ = c (z - h)
 // M receives q_inv H^T H in its (q,q), (d1,q) and (d2,q) entries (packed lower 6x6; the
@@ -25,18 +26,13 @@ namespace pnp {
 // summed, ss the sum of c^2 r^2.
 __device__ __forceinline__ void qeif_point(double (&M)[21], double (&g)[6], double &ss,
                                            const double (&qs)[4], const double (&hq)[4], double c,
-                                           double d1, double d2, double X, double Y, double Z,
+                                           double ncd1, double ncd2, double X, double Y, double Z,
                                            double bx, double by)
 {
     const double s0 = __builtin_fma(X, qs[0], __builtin_fma(-Y, qs[3], Z * qs[2]));
     const double s1 = __builtin_fma(X, qs[1], __builtin_fma(Y, qs[2], Z * qs[3]));
     const double s2 = __builtin_fma(-X, qs[2], __builtin_fma(Y, qs[1], Z * qs[0]));
     const double s3 = __builtin_fma(-X, qs[3], __builtin_fma(-Y, qs[0], Z * qs[1]));
-    const double p1 = __builtin_fma(s0, hq[0], __builtin_fma(s1, hq[1], __builtin_fma(s2, hq[2], s3 * hq[3])));
-    const double p2 = __builtin_fma(-s3, hq[0], __builtin_fma(-s2, hq[1], __builtin_fma(s1, hq[2], s0 * hq[3])));
-    const double p3 = __builtin_fma(s2, hq[0], __builtin_fma(-s3, hq[1], __builtin_fma(-s0, hq[2], s1 * hq[3])));
-    const double rx = __builtin_fma(c, bx - d1, -__builtin_fma(-bx, p3, p1));
-    const double ry = __builtin_fma(c, by - d2, -__builtin_fma(-by, p3, p2));
     double u[4], v[4];
     u[0] = __builtin_fma(-bx, s2, s0);
     u[1] = __builtin_fma(bx, s3, s1);
@@ -46,6 +42,14 @@ __device__ __forceinline__ void qeif_point(double (&M)[21], double (&g)[6], doub
     v[1] = __builtin_fma(by, s3, -s2);
     v[2] = __builtin_fma(by, s0, s1);
     v[3] = __builtin_fma(-by, s1, s0);
+    // the model is a quadratic form in q, so its value is half its own Jacobian row times q:
+    // c h_x = u~ . q/2 + c d1, and the residual needs no separate evaluation of P phi_j
+    double rx = __builtin_fma(c, bx, ncd1), ry = __builtin_fma(c, by, ncd2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        rx = __builtin_fma(-u[i], hq[i], rx);
+        ry = __builtin_fma(-v[i], hq[i], ry);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -89,18 +93,21 @@ __device__ __forceinline__ void gamma_matrix(const double (&x)[6], double (&phi)
 //                    res   = |r|                           (residual BEFORE the update)
 //                    Sigma = Omega^-1 ;  x += Sigma * (q_inv * H^T r)
 //                    stop if |res - res_old| < rel_tol * res_old, else res_old = res
+//                    (evaluated on the squared residuals, see QeifRule)
 // The reference forms zeta = Obar x + q_inv H^T (z - h + H x) and x = Sigma zeta; since
 // Omega = Obar + q_inv H^T H these are the same vector, x + Sigma q_inv H^T (z - h).
 // Its stopping rule |(res - res_old)/res_old| < rel_tol is the same inequality (res_old > 0).
 struct QeifState {
-    double x[6];     // [q(4), delta1, delta2]
-    double T[21];    // packed lower 6x6; holds -Sigma between iterations (see qeif_iterate)
-    double res_old;  // residual norm of the previous iteration
-    double res;      // residual norm at the last linearisation point
-    int k;           // iterations done
+    double x[6];    // [q(4), delta1, delta2]
+    double T[21];   // packed lower 6x6; holds -Sigma between iterations (see qeif_iterate)
+    double ss_old;  // squared residual norm of the previous iteration, in the solver's units
+    double ss;      // squared residual norm at the last linearisation point, same units
+    int k;          // iterations done
 };
 
-__device__ __forceinline__ void qeif_init(QeifState &st, const QeifParams &p)
+// unit2: square of the factor by which the solver scales its residuals (q_inv in the point
+// form, which carries c (z - h); 1 in the moment form).
+__device__ __forceinline__ void qeif_init(QeifState &st, const QeifParams &p, double unit2)
 {
     st.x[0] = 1.0;
 #pragma unroll
@@ -110,17 +117,77 @@ __device__ __forceinline__ void qeif_init(QeifState &st, const QeifParams &p)
     const double s0 = -1.0 / p.omega0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) st.T[tri(i, i)] = s0;
-    st.res_old = p.res_old0;
-    st.res = 1.0e5;
+    st.ss_old = p.res_old0 * p.res_old0 * unit2;
+    st.ss = 1.0e10 * unit2;  // reported as a residual of 1e5 when no iteration runs
     st.k = 0;
 }
+
+// The stopping rule |res - res_old| < rel_tol res_old on squared residuals (no square root in
+// the loop): with res, res_old >= 0 it reads (1 - tol) res_old < res < (1 + tol) res_old, i.e.
+// lo2 ss_old < ss < hi2 ss_old.  A bound whose factor is not positive is always (lower) or
+// never (upper) met for res_old > 0, which the negative stand-ins below reproduce; res_old = 0
+// and NaN never stop, as in the original form.
+struct QeifRule {
+    double lo2, hi2;
+    __device__ __forceinline__ explicit QeifRule(const QeifParams &p)
+    {
+        const double lo = 1.0 - p.rel_tol, hi = 1.0 + p.rel_tol;
+        lo2 = lo > 0.0 ? lo * lo : (lo < 0.0 ? -1.0 : 0.0);
+        hi2 = hi > 0.0 ? hi * hi : -1.0;
+    }
+};
 
 // Scalars derived from the parameters once per kernel.
 struct QeifConsts {
     double c, c_inv, dd;  // sqrt(q_inv), its reciprocal, q_inv * N
+    QeifRule rule;
     __device__ __forceinline__ QeifConsts(const QeifParams &p, int N)
-        : c(sqrt(p.q_inv)), c_inv(1.0 / sqrt(p.q_inv)), dd(p.q_inv * static_cast<double>(N)) {}
+        : c(sqrt(p.q_inv)), c_inv(1.0 / sqrt(p.q_inv)), dd(p.q_inv * static_cast<double>(N)), rule(p) {}
 };
+
+// Predict step: T = -Sigma on entry, Obar = (Sigma + R_p)^-1 on exit.  Sigma_0 is a multiple of
+// the identity, so in the first iteration the sweep reduces to two reciprocals.
+__device__ __forceinline__ void qeif_predict(QeifState &st, const QeifParams &p)
+{
+    double(&T)[21] = st.T;
+    ++st.k;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) T[tri(i, i)] -= p.r_quat;
+    T[tri(4, 4)] -= p.r_delta;
+    T[tri(5, 5)] -= p.r_delta;
+    if (st.k == 1) {
+        const double oq = -rcp(T[tri(0, 0)]), od = -rcp(T[tri(4, 4)]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) T[tri(i, i)] = oq;
+        T[tri(4, 4)] = od;
+        T[tri(5, 5)] = od;
+    } else {
+        sweep_neg_inverse<6>(T);
+    }
+}
+
+// Correct step: T = Omega on entry and -Sigma on exit; x += Sigma g; returns true when the
+// stopping rule fires on the squared residual ss of the linearisation point just used.
+__device__ __forceinline__ bool qeif_correct(QeifState &st, const double (&g)[6], double ss, const QeifRule &rule)
+{
+    double(&T)[21] = st.T;
+    sweep_neg_inverse<6>(T);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) st.x[i] = __builtin_fma(-T[i >= j ? tri(i, j) : tri(j, i)], g[j], st.x[i]);
+    }
+    const bool stop = (ss > rule.lo2 * st.ss_old) && (ss < rule.hi2 * st.ss_old);
+    st.ss = ss;
+    st.ss_old = ss;
+    return stop;
+}
+
+// Residual norm of the last linearisation point; unit_inv = 1 / sqrt(unit2) of qeif_init.
+__device__ __forceinline__ double qeif_residual(const QeifState &st, double unit_inv)
+{
+    return sqrt_pos(st.ss) * unit_inv;
+}
 
 // One iteration; returns true when the stopping rule fires.  T is swept twice and changes
 // sign each time: -Sigma on entry, Obar after the first sweep, -Sigma again on exit.
@@ -131,16 +198,11 @@ __device__ __forceinline__ bool qeif_iterate(QeifState &st, const PointFetch &pt
     double(&x)[6] = st.x;
     double(&T)[21] = st.T;
     const double c = kc.c;
-    ++st.k;
-    // predict: -(Sigma + R_p), then sweep -> (Sigma + R_p)^-1 = Obar
-#pragma unroll
-    for (int i = 0; i < 4; ++i) T[tri(i, i)] -= p.r_quat;
-    T[tri(4, 4)] -= p.r_delta;
-    T[tri(5, 5)] -= p.r_delta;
-    sweep_neg_inverse<6>(T);
+    qeif_predict(st, p);
     // update: Omega = Obar + q_inv H^T H, accumulated point by point
     const double qs[4] = {2.0 * c * x[0], 2.0 * c * x[1], 2.0 * c * x[2], 2.0 * c * x[3]};
     const double hq[4] = {0.5 * x[0], 0.5 * x[1], 0.5 * x[2], 0.5 * x[3]};
+    const double ncd1 = -c * x[4], ncd2 = -c * x[5];
     double g[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     double ss = 0.0;
     if constexpr (LPI == 1) {
@@ -149,13 +211,13 @@ __device__ __forceinline__ bool qeif_iterate(QeifState &st, const PointFetch &pt
             for (int i = 0; i < NCT; ++i) {
                 double X, Y, Z, bx, by;
                 pts(i, X, Y, Z, bx, by);
-                qeif_point(T, g, ss, qs, hq, c, x[4], x[5], X, Y, Z, bx, by);
+                qeif_point(T, g, ss, qs, hq, c, ncd1, ncd2, X, Y, Z, bx, by);
             }
         } else {
             for (int i = 0; i < N; ++i) {
                 double X, Y, Z, bx, by;
                 pts(i, X, Y, Z, bx, by);
-                qeif_point(T, g, ss, qs, hq, c, x[4], x[5], X, Y, Z, bx, by);
+                qeif_point(T, g, ss, qs, hq, c, ncd1, ncd2, X, Y, Z, bx, by);
             }
         }
     } else {
@@ -165,7 +227,7 @@ __device__ __forceinline__ bool qeif_iterate(QeifState &st, const PointFetch &pt
         for (int i = lane_in_group; i < N; i += LPI) {
             double X, Y, Z, bx, by;
             pts(i, X, Y, Z, bx, by);
-            qeif_point(M, g, ss, qs, hq, c, x[4], x[5], X, Y, Z, bx, by);
+            qeif_point(M, g, ss, qs, hq, c, ncd1, ncd2, X, Y, Z, bx, by);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -182,18 +244,7 @@ __device__ __forceinline__ bool qeif_iterate(QeifState &st, const PointFetch &pt
     T[tri(5, 5)] += kc.dd;
     g[4] *= c;
     g[5] *= c;
-    st.res = sqrt_pos(ss) * kc.c_inv;
-    sweep_neg_inverse<6>(T);  // T = -Sigma
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        double dx = 0.0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) dx = __builtin_fma(T[i >= j ? tri(i, j) : tri(j, i)], g[j], dx);
-        x[i] -= dx;
-    }
-    const bool stop = fabs(st.res - st.res_old) < p.rel_tol * st.res_old;
-    st.res_old = st.res;
-    return stop;
+    return qeif_correct(st, g, ss, kc.rule);
 }
 
 // reconstruct: R = Gamma(q)/gamma, t3 = 1/gamma, t = [d1, d2, 1] t3
@@ -215,13 +266,13 @@ __device__ __forceinline__ void qeif_solve(const PointFetch &pts, int N, int lan
                                            double &res_out, int &iters_out)
 {
     QeifState st;
-    qeif_init(st, p);
+    qeif_init(st, p, p.q_inv);
     const QeifConsts kc(p, N);
     while (st.k < p.max_it) {
         if (qeif_iterate<LPI, NCT>(st, pts, N, lane_in_group, p, kc)) break;
     }
     qeif_finish(st, R, t);
-    res_out = st.res;
+    res_out = qeif_residual(st, kc.c_inv);
     iters_out = st.k;
 }
 
@@ -370,16 +421,12 @@ __device__ __forceinline__ void moment_axis_terms(const double (&S0)[6], const d
 // returns the point-by-point sum of squared residuals at the current x.
 template <typename ExactResidual>
 __device__ __forceinline__ bool qeif_moment_iterate(QeifState &st, const Moments &M, double n,
-                                                    const QeifParams &p, const ExactResidual &exact_ss)
+                                                    const QeifParams &p, const QeifRule &rule,
+                                                    const ExactResidual &exact_ss)
 {
     double(&x)[6] = st.x;
     double(&T)[21] = st.T;
-    ++st.k;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) T[tri(i, i)] -= p.r_quat;
-    T[tri(4, 4)] -= p.r_delta;
-    T[tri(5, 5)] -= p.r_delta;
-    sweep_neg_inverse<6>(T);  // Obar
+    qeif_predict(st, p);  // Obar
 
     double phi[9], gamma;
     gamma_matrix(x, phi, gamma);
@@ -411,18 +458,7 @@ __device__ __forceinline__ bool qeif_moment_iterate(QeifState &st, const Moments
     T[tri(5, 5)] = __builtin_fma(w, n, T[tri(5, 5)]);
     const double g[6] = {w * (gax[0] + gay[0]), w * (gax[1] + gay[1]), w * (gax[2] + gay[2]),
                          w * (gax[3] + gay[3]), w * gdx, w * gdy};
-    st.res = sqrt_pos(ss);
-    sweep_neg_inverse<6>(T);  // -Sigma
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        double dx = 0.0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) dx = __builtin_fma(T[i >= j ? tri(i, j) : tri(j, i)], g[j], dx);
-        x[i] -= dx;
-    }
-    const bool stop = fabs(st.res - st.res_old) < p.rel_tol * st.res_old;
-    st.res_old = st.res;
-    return stop;
+    return qeif_correct(st, g, ss, rule);
 }
 
 }  // namespace pnp
