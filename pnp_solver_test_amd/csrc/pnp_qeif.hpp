@@ -24,31 +24,48 @@ namespace pnp {
 // M receives q_inv H^T H in its (q,q), (d1,q) and (d2,q) entries (packed lower 6x6; the
 // constant (d,d) block q_inv*N*I is added by the caller); g receives [c^2 H_q^T r, c r_x, c r_y]
 // summed, ss the sum of c^2 r^2.
+template <bool FIRST = false>
 __device__ __forceinline__ void qeif_point(double (&M)[21], double (&g)[6], double &ss,
                                            const double (&qs)[4], const double (&hq)[4], double c,
                                            double ncd1, double ncd2, double X, double Y, double Z,
                                            double bx, double by)
 {
-    const double s0 = __builtin_fma(X, qs[0], __builtin_fma(-Y, qs[3], Z * qs[2]));
-    const double s1 = __builtin_fma(X, qs[1], __builtin_fma(Y, qs[2], Z * qs[3]));
-    const double s2 = __builtin_fma(-X, qs[2], __builtin_fma(Y, qs[1], Z * qs[0]));
-    const double s3 = __builtin_fma(-X, qs[3], __builtin_fma(-Y, qs[0], Z * qs[1]));
-    double u[4], v[4];
-    u[0] = __builtin_fma(-bx, s2, s0);
-    u[1] = __builtin_fma(bx, s3, s1);
-    u[2] = __builtin_fma(bx, s0, s2);
-    u[3] = __builtin_fma(-bx, s1, s3);
-    v[0] = __builtin_fma(-by, s2, -s3);
-    v[1] = __builtin_fma(by, s3, -s2);
-    v[2] = __builtin_fma(by, s0, s1);
-    v[3] = __builtin_fma(-by, s1, s0);
-    // the model is a quadratic form in q, so its value is half its own Jacobian row times q:
-    // c h_x = u~ . q/2 + c d1, and the residual needs no separate evaluation of P phi_j
-    double rx = __builtin_fma(c, bx, ncd1), ry = __builtin_fma(c, by, ncd2);
+    double u[4], v[4], rx, ry;
+    if constexpr (FIRST) {
+        // at the initial state q = (1, 0, 0, 0), delta = 0: s = qs0 (X, 0, Z, -Y)
+        const double s0 = X * qs[0], s2 = Z * qs[0], s3 = -(Y * qs[0]);
+        u[0] = __builtin_fma(-bx, s2, s0);
+        u[1] = bx * s3;
+        u[2] = __builtin_fma(bx, s0, s2);
+        u[3] = s3;
+        v[0] = __builtin_fma(-by, s2, -s3);
+        v[1] = __builtin_fma(by, s3, -s2);
+        v[2] = by * s0;
+        v[3] = s0;
+        rx = __builtin_fma(-u[0], hq[0], c * bx);
+        ry = __builtin_fma(-v[0], hq[0], c * by);
+    } else {
+        const double s0 = __builtin_fma(X, qs[0], __builtin_fma(-Y, qs[3], Z * qs[2]));
+        const double s1 = __builtin_fma(X, qs[1], __builtin_fma(Y, qs[2], Z * qs[3]));
+        const double s2 = __builtin_fma(-X, qs[2], __builtin_fma(Y, qs[1], Z * qs[0]));
+        const double s3 = __builtin_fma(-X, qs[3], __builtin_fma(-Y, qs[0], Z * qs[1]));
+        u[0] = __builtin_fma(-bx, s2, s0);
+        u[1] = __builtin_fma(bx, s3, s1);
+        u[2] = __builtin_fma(bx, s0, s2);
+        u[3] = __builtin_fma(-bx, s1, s3);
+        v[0] = __builtin_fma(-by, s2, -s3);
+        v[1] = __builtin_fma(by, s3, -s2);
+        v[2] = __builtin_fma(by, s0, s1);
+        v[3] = __builtin_fma(-by, s1, s0);
+        // the model is a quadratic form in q, so its value is half its own Jacobian row times q:
+        // c h_x = u~ . q/2 + c d1, and the residual needs no separate evaluation of P phi_j
+        rx = __builtin_fma(c, bx, ncd1);
+        ry = __builtin_fma(c, by, ncd2);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        rx = __builtin_fma(-u[i], hq[i], rx);
-        ry = __builtin_fma(-v[i], hq[i], ry);
+        for (int i = 0; i < 4; ++i) {
+            rx = __builtin_fma(-u[i], hq[i], rx);
+            ry = __builtin_fma(-v[i], hq[i], ry);
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -147,6 +164,7 @@ struct QeifConsts {
 
 // Predict step: T = -Sigma on entry, Obar = (Sigma + R_p)^-1 on exit.  Sigma_0 is a multiple of
 // the identity, so in the first iteration the sweep reduces to two reciprocals.
+template <bool FIRST>
 __device__ __forceinline__ void qeif_predict(QeifState &st, const QeifParams &p)
 {
     double(&T)[21] = st.T;
@@ -155,7 +173,7 @@ __device__ __forceinline__ void qeif_predict(QeifState &st, const QeifParams &p)
     for (int i = 0; i < 4; ++i) T[tri(i, i)] -= p.r_quat;
     T[tri(4, 4)] -= p.r_delta;
     T[tri(5, 5)] -= p.r_delta;
-    if (st.k == 1) {
+    if constexpr (FIRST) {
         const double oq = -rcp(T[tri(0, 0)]), od = -rcp(T[tri(4, 4)]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) T[tri(i, i)] = oq;
@@ -191,14 +209,16 @@ __device__ __forceinline__ double qeif_residual(const QeifState &st, double unit
 
 // One iteration; returns true when the stopping rule fires.  T is swept twice and changes
 // sign each time: -Sigma on entry, Obar after the first sweep, -Sigma again on exit.
-template <int LPI, int NCT, typename PointFetch>
+// FIRST: the iteration that starts from the state qeif_init leaves (x = [1,0,0,0,0,0], Sigma a
+// multiple of the identity), for which the predict step and the point terms simplify.
+template <int LPI, int NCT, bool FIRST, typename PointFetch>
 __device__ __forceinline__ bool qeif_iterate(QeifState &st, const PointFetch &pts, int N, int lane_in_group,
                                              const QeifParams &p, const QeifConsts &kc)
 {
     double(&x)[6] = st.x;
     double(&T)[21] = st.T;
     const double c = kc.c;
-    qeif_predict(st, p);
+    qeif_predict<FIRST>(st, p);
     // update: Omega = Obar + q_inv H^T H, accumulated point by point
     const double qs[4] = {2.0 * c * x[0], 2.0 * c * x[1], 2.0 * c * x[2], 2.0 * c * x[3]};
     const double hq[4] = {0.5 * x[0], 0.5 * x[1], 0.5 * x[2], 0.5 * x[3]};
@@ -211,13 +231,13 @@ __device__ __forceinline__ bool qeif_iterate(QeifState &st, const PointFetch &pt
             for (int i = 0; i < NCT; ++i) {
                 double X, Y, Z, bx, by;
                 pts(i, X, Y, Z, bx, by);
-                qeif_point(T, g, ss, qs, hq, c, ncd1, ncd2, X, Y, Z, bx, by);
+                qeif_point<FIRST>(T, g, ss, qs, hq, c, ncd1, ncd2, X, Y, Z, bx, by);
             }
         } else {
             for (int i = 0; i < N; ++i) {
                 double X, Y, Z, bx, by;
                 pts(i, X, Y, Z, bx, by);
-                qeif_point(T, g, ss, qs, hq, c, ncd1, ncd2, X, Y, Z, bx, by);
+                qeif_point<FIRST>(T, g, ss, qs, hq, c, ncd1, ncd2, X, Y, Z, bx, by);
             }
         }
     } else {
@@ -227,7 +247,7 @@ __device__ __forceinline__ bool qeif_iterate(QeifState &st, const PointFetch &pt
         for (int i = lane_in_group; i < N; i += LPI) {
             double X, Y, Z, bx, by;
             pts(i, X, Y, Z, bx, by);
-            qeif_point(M, g, ss, qs, hq, c, ncd1, ncd2, X, Y, Z, bx, by);
+            qeif_point<FIRST>(M, g, ss, qs, hq, c, ncd1, ncd2, X, Y, Z, bx, by);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -268,8 +288,10 @@ __device__ __forceinline__ void qeif_solve(const PointFetch &pts, int N, int lan
     QeifState st;
     qeif_init(st, p, p.q_inv);
     const QeifConsts kc(p, N);
-    while (st.k < p.max_it) {
-        if (qeif_iterate<LPI, NCT>(st, pts, N, lane_in_group, p, kc)) break;
+    if (p.max_it > 0 && !qeif_iterate<LPI, NCT, true>(st, pts, N, lane_in_group, p, kc)) {
+        while (st.k < p.max_it) {
+            if (qeif_iterate<LPI, NCT, false>(st, pts, N, lane_in_group, p, kc)) break;
+        }
     }
     qeif_finish(st, R, t);
     res_out = qeif_residual(st, kc.c_inv);
@@ -426,7 +448,10 @@ __device__ __forceinline__ bool qeif_moment_iterate(QeifState &st, const Moments
 {
     double(&x)[6] = st.x;
     double(&T)[21] = st.T;
-    qeif_predict(st, p);  // Obar
+    if (st.k == 0)  // Obar
+        qeif_predict<true>(st, p);
+    else
+        qeif_predict<false>(st, p);
 
     double phi[9], gamma;
     gamma_matrix(x, phi, gamma);
