@@ -44,11 +44,16 @@ SPINUP_STEPS = 100   # untimed launches before the W warm-up steps (see main)
 
 
 def qeif_flops(n_points, iters_mean):
-    """float64 flops (fma = 2) the kernel executes per solve: per iteration 78 fused ops per
-    point (shared Jacobian products, model, residual, sums straight into the information
-    matrix), two packed 6x6 symmetric sweeps (150 each) and ~60 for the state update, the
-    residual norm and the stopping rule."""
-    return 2.0 * iters_mean * (78.0 * n_points + 2 * 150.0 + 60.0)
+    """float64 flops the point-form kernel executes per solve (fma = 2, multiply / add /
+    reciprocal seed = 1), counted from its instruction listing.  Per iteration: 64 fma + 6 single
+    operations per point (shared Jacobian products, residual from the Jacobian row, sums straight
+    into the information matrix) = 134 flops; two packed 6x6 symmetric sweeps of 108 fma + 36
+    single = 252 flops each; 36 fma + 22 single = 94 flops for the state update and the stopping
+    rule.  The first iteration starts from q = (1,0,0,0) with a diagonal covariance: 97 flops per
+    point, and 20 flops instead of its first sweep."""
+    rest = 134.0 * n_points + 2 * 252.0 + 94.0
+    first = 97.0 * n_points + 252.0 + 20.0 + 94.0
+    return max(iters_mean - 1.0, 0.0) * rest + first
 
 
 def qeif_moment_flops(n_points, iters_mean):

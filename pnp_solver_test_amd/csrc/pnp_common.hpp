@@ -8,11 +8,17 @@
 
 namespace pnp {
 
-constexpr int kBlock = 256;
-// Threads per workgroup of the solver kernels for element type T: 256 for float, 128 for double,
-// so that a workgroup's staged correspondences take the same LDS bytes either way.
+constexpr int kBlock = 256;  // threads per workgroup of the element-wise kernels
+// Threads per workgroup of the point-form solver kernels for element type T: 128 for float, 64
+// for double, so that a workgroup's staged correspondences take the same LDS bytes either way.
+// Two wavefronts per workgroup: a workgroup's slots free up when its slower wavefront ends, so
+// small workgroups keep the SIMDs fuller through the spread of iteration counts than the 256
+// threads the moment kernel wants for its staging geometry.
 template <typename T>
-constexpr int kSolveBlock = kBlock * static_cast<int>(sizeof(float)) / static_cast<int>(sizeof(T));
+constexpr int kSolveBlock = 512 / static_cast<int>(sizeof(T));
+// Threads per workgroup of the moment-form kernel: 256 for float, 128 for double.
+template <typename T>
+constexpr int kMomentBlock = 1024 / static_cast<int>(sizeof(T));
 
 #ifndef PNP_QEIF_WAVES
 #define PNP_QEIF_WAVES 2  // minimum resident waves per SIMD the QEIF kernels are compiled for

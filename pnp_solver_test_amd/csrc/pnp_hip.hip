@@ -115,7 +115,7 @@ int kinv_rows(const double K[9], pnp::KinvRows &ki)
 
 size_t lds_bytes(int lpi, int N, bool per_problem_xyz, int n_patterns, size_t elem)
 {
-    const size_t pb = (kBlock * sizeof(float) / elem) / lpi;   // pnp::kSolveBlock<T> / lpi
+    const size_t pb = (512 / elem) / lpi;   // pnp::kSolveBlock<T> / lpi
     const size_t uv = pb * 2 * N;
     const size_t xyz = per_problem_xyz ? pb * 3 * N : static_cast<size_t>(n_patterns) * 3 * N;
     return (uv + xyz) * elem;
@@ -183,7 +183,7 @@ template <typename T>
 int launch_qeif_moment(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, const pnp::KinvRows &ki,
                        int64_t B, int N, const pnp::QeifParams &p, T *R, T *t, T *res, int32_t *iters, T *rpy)
 {
-    constexpr int block = pnp::kSolveBlock<T>;
+    constexpr int block = pnp::kMomentBlock<T>;
     constexpr size_t row = block + 1;
     constexpr int c_own = pnp::kMomentChunkOwn<T>, c_shared = pnp::kMomentChunkShared<T>;
     const int64_t nblk = (B + block - 1) / block;

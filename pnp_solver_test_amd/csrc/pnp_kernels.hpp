@@ -2,7 +2,7 @@
 // correspondences, register-resident 6x6 / 4x4 algebra, no MFMA (the per-problem matrices
 // are far too small to form a dense contraction).
 //
-// Work decomposition.  A workgroup of 256 threads owns PB = 256/LPI consecutive problems,
+// Work decomposition.  A workgroup of 128 threads owns PB = 128/LPI consecutive problems,
 // LPI ("lanes per problem") being a power of two between 1 and 64.  The workgroup first
 // copies its problems' correspondences (one contiguous range of the uv array, and of the
 // xyz array when every problem has its own pattern) into LDS with coalesced 16-byte loads.
@@ -225,12 +225,12 @@ constexpr int kMomentChunkShared = 64 / static_cast<int>(sizeof(T));
 // Dynamic LDS: SHARED ? 2 C (BLOCK + 1) elements, rounded up to 8 bytes, + 9 N doubles
 //                     : 5 C (BLOCK + 1) elements.
 template <typename T, int C, bool SHARED>
-__global__ __launch_bounds__(kSolveBlock<T>, PNP_QEIF_WAVES) void qeif_moment_kernel(
+__global__ __launch_bounds__(kMomentBlock<T>, PNP_QEIF_WAVES) void qeif_moment_kernel(
     const T *__restrict__ uv, const T *__restrict__ xyz, int64_t xyz_stride, KinvRows ki, int64_t B, int N,
     QeifParams p, T *__restrict__ R_out, T *__restrict__ t_out, T *__restrict__ res_out,
     int32_t *__restrict__ iters_out, T *__restrict__ rpy_out)
 {
-    constexpr int BLOCK = kSolveBlock<T>;
+    constexpr int BLOCK = kMomentBlock<T>;
     constexpr int ROW = BLOCK + 1;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     T *s_uv = reinterpret_cast<T *>(lds_raw);

@@ -83,7 +83,7 @@ def test_lanes_per_problem_heuristic():
     lib = _lib.load()
     lib.pnp_set_lanes_per_problem(0)
     assert lib.pnp_get_lanes_per_problem(1 << 20, 6, 18) == 1      # a lane per problem
-    assert lib.pnp_get_lanes_per_problem(1 << 18, 68, 0) >= 4      # LDS bound for 68 points
+    assert lib.pnp_get_lanes_per_problem(1 << 18, 68, 0) >= 2      # LDS bound for 68 points
     assert lib.pnp_get_lanes_per_problem(1, 68, 0) == 64           # one wavefront per problem
     assert lib.pnp_get_lanes_per_problem(1, 6, 0) >= 2
 
