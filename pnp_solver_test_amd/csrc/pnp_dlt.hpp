@@ -51,6 +51,14 @@ __device__ __forceinline__ void dlt_block_reconstruct(const double (&f)[8], doub
     t[2] = gi;
 }
 
+// Delta_i = theta_i . phi3 + 1, kept away from zero by +-1e-7
+__device__ __forceinline__ double dlt_depth_factor(double X, double Y, double Z, const double (&phi3)[3])
+{
+    const double Dl = __builtin_fma(X, phi3[0], __builtin_fma(Y, phi3[1], __builtin_fma(Z, phi3[2], 1.0)));
+    // (Dl is never -0: a sum that cancels exactly rounds to +0)
+    return (fabs(Dl) <= 1e-7) ? __builtin_copysign(1e-7, Dl) : Dl;
+}
+
 // One problem's DLT solve.  The reference's (2N x 8) system A phi = B has x rows that touch
 // only columns {0,1,2,6} and y rows that touch only {3,4,5,7}, with the same coefficients
 // d_i = [theta_i/Delta_i, 1/Delta_i]: it is two (N x 4) least-squares problems sharing one
@@ -75,9 +83,7 @@ __device__ __forceinline__ void dlt_solve(const PointFetch &pts, int N, int lane
         auto accumulate = [&](int i) {
             double X, Y, Z, bx, by;
             pts(i, X, Y, Z, bx, by);
-            double Dl = __builtin_fma(X, phi3[0], __builtin_fma(Y, phi3[1], Z * phi3[2])) + 1.0;
-            if (fabs(Dl) <= 1e-7) Dl = (Dl < 0.0) ? -1e-7 : 1e-7;
-            const double w = rcp(Dl);
+            const double w = rcp(dlt_depth_factor(X, Y, Z, phi3));
             const double d[4] = {X * w, Y * w, Z * w, w};
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
@@ -113,9 +119,7 @@ __device__ __forceinline__ void dlt_solve(const PointFetch &pts, int N, int lane
             auto residual = [&](int i) {
                 double X, Y, Z, bx, by;
                 pts(i, X, Y, Z, bx, by);
-                double Dl = __builtin_fma(X, phi3[0], __builtin_fma(Y, phi3[1], Z * phi3[2])) + 1.0;
-                if (fabs(Dl) <= 1e-7) Dl = (Dl < 0.0) ? -1e-7 : 1e-7;
-                const double w = rcp(Dl);
+                const double w = rcp(dlt_depth_factor(X, Y, Z, phi3));
                 const double ex = bx - w * __builtin_fma(X, fx[0], __builtin_fma(Y, fx[1], __builtin_fma(Z, fx[2], fx[3])));
                 const double ey = by - w * __builtin_fma(X, fy[0], __builtin_fma(Y, fy[1], __builtin_fma(Z, fy[2], fy[3])));
                 ss = __builtin_fma(ex, ex, __builtin_fma(ey, ey, ss));
