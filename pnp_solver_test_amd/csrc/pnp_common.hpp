@@ -167,8 +167,12 @@ __device__ __forceinline__ void euler_deg(const double (&R)[9], double &roll, do
     constexpr double kPi = 3.14159265358979323846;
     constexpr double kHalfPi = kPi / 2.0;
     constexpr double kR2D = 180.0 / kPi;
+    // |pi/2 - asin(a)| <= 1e-7 holds for exactly the doubles 1 - 45 * 2^-53 <= a <= 1 (above 1 the
+    // arcsine is NaN and the test fails): the gimbal test needs no arcsine.
+    constexpr double kGimbalMin = 1.0 - 45.0 * 0x1p-53;
+    const double a7 = fabs(R[7]);
     double th1, th2, th3;
-    if (fabs(kHalfPi - asin(fabs(R[7]))) <= 1e-7) {
+    if (a7 >= kGimbalMin && a7 <= 1.0) {
         const double s = (-R[7] > 0.0) ? 1.0 : ((-R[7] < 0.0) ? -1.0 : 0.0);
         th2 = s * kHalfPi;
         th3 = 0.0;
@@ -176,8 +180,11 @@ __device__ __forceinline__ void euler_deg(const double (&R)[9], double &roll, do
     } else {
         th1 = atan2(R[1], R[4]);
         th3 = atan2(R[6], R[8]);
-        const double c1 = cos(th1), c3 = cos(th3);
-        const double c2 = (fabs(c1) > fabs(c3)) ? R[4] / c1 : R[8] / c3;
+        // cos(th1) = R4 / h1 and cos(th3) = R8 / h3 with h1 = |(R1, R4)|, h3 = |(R6, R8)|: dividing
+        // R4 (R8) by the cosine of larger magnitude, as the reference does, returns h1 (h3).
+        const double h1 = sqrt_pos(__builtin_fma(R[1], R[1], R[4] * R[4]));
+        const double h3 = sqrt_pos(__builtin_fma(R[6], R[6], R[8] * R[8]));
+        const double c2 = (fabs(R[4]) * h3 > fabs(R[8]) * h1) ? h1 : h3;
         th2 = atan2(-R[7], c2);
     }
     roll = th1 * kR2D;
