@@ -250,6 +250,25 @@ def test_euler_kernel(golden, torch_dev):
     assert np.allclose(got[:, 2], [90.0, -90.0]) and np.all(got[:, 1] == 0.0)
 
 
+def test_euler_gimbal_threshold_matches_the_arcsine_test():
+    """The kernel decides the gimbal branch by comparing |R21| with 1 - 45 * 2^-53 instead of
+    evaluating |pi/2 - asin|R21|| <= 1e-7 (PNP_SOLVER_LIB.py:4482): same branch for every double
+    around the threshold, including values above 1 (arcsine NaN -> general branch)."""
+    base = po.euler_to_R(20.0, 5.0, 80.0, True)
+    ks = np.arange(-3, 60)
+    R = np.repeat(base[None], 2 * len(ks), axis=0)
+    R[:len(ks), 2, 1] = -(1.0 - ks * 2.0 ** -53)
+    R[len(ks):, 2, 1] = 1.0 - ks * 2.0 ** -53
+    with np.errstate(invalid="ignore"):
+        ref = c_oracle.euler_deg(R)
+    got = pnp.euler_deg_batch(R)
+    assert got.dtype == np.float64
+    locked = np.abs(np.abs(ref[:, 2]) - 90.0) < 1e-12
+    assert 40 < locked.sum() < 2 * len(ks) - 20          # both branches are exercised
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.allclose(got, ref, atol=1e-9, equal_nan=True)
+
+
 # ---------------------------------------------------------------------------------------------
 # boundary behaviour and edge cases
 # ---------------------------------------------------------------------------------------------
