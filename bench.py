@@ -47,12 +47,13 @@ def qeif_flops(n_points, iters_mean):
     """float64 flops the point-form kernel executes per solve (fma = 2, multiply / add /
     reciprocal seed = 1), counted from its instruction listing.  Per iteration: 64 fma + 6 single
     operations per point (shared Jacobian products, residual from the Jacobian row, sums straight
-    into the information matrix) = 134 flops; two packed 6x6 symmetric sweeps of 108 fma + 36
-    single = 252 flops each; 36 fma + 22 single = 94 flops for the state update and the stopping
-    rule.  The first iteration starts from q = (1,0,0,0) with a diagonal covariance: 97 flops per
-    point, and 20 flops instead of its first sweep."""
-    rest = 134.0 * n_points + 2 * 252.0 + 94.0
-    first = 97.0 * n_points + 252.0 + 20.0 + 94.0
+    into the information matrix) = 134 flops; 501 flops for the rest (N = 6 loop body: 582 fma,
+    104 multiplies, 25 adds, 12 reciprocal seeds): one packed 6x6 symmetric sweep with the
+    21-entry rescaling of the predict step, one LDL^T solve, state update and stopping rule.  The
+    first iteration starts from q = (1,0,0,0) with a diagonal information matrix: 97 flops per
+    point and no sweep."""
+    rest = 134.0 * n_points + 501.0
+    first = 97.0 * n_points + 225.0
     return max(iters_mean - 1.0, 0.0) * rest + first
 
 

@@ -54,6 +54,7 @@ typedef struct pnp_qeif_params {
     double r_quat;    /* process noise added to the quaternion block each step -> 0.1   */
     double r_delta;   /* process noise added to delta_1, delta_2               -> 0.01  */
     double omega0;    /* initial information matrix = omega0 * I               -> 1e-5  */
+                      /* q_inv, r_quat, r_delta and omega0 must be > 0 (PNP_E_ARG otherwise) */
     int32_t max_it;   /* iteration cap                                         -> 14    */
     double rel_tol;   /* stop when |res - res_old| / res_old < rel_tol         -> 1e-2  */
     double res_old0;  /* initial res_old                                       -> 1e-7  */

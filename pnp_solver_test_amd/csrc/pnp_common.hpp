@@ -105,6 +105,86 @@ __device__ __forceinline__ void sweep_neg_inverse(double (&a)[n * (n + 1) / 2])
     }
 }
 
+// o <- -((a + diag(sh))^-1) for a symmetric definite n x n matrix, a left untouched: the first
+// pivot is swept out of place (reading a, writing o), the others in place on o, so that keeping
+// a costs no register copies.
+template <int n>
+__device__ __forceinline__ void sweep_neg_inverse_shifted(const double (&a)[n * (n + 1) / 2],
+                                                          const double (&sh)[n], double (&o)[n * (n + 1) / 2])
+{
+    {
+        const double dinv = rcp(a[0] + sh[0]);
+        double t[n];
+#pragma unroll
+        for (int i = 1; i < n; ++i) t[i] = a[tri(i, 0)] * dinv;
+#pragma unroll
+        for (int i = 1; i < n; ++i) {
+#pragma unroll
+            for (int j = 1; j <= i; ++j)
+                o[tri(i, j)] = __builtin_fma(-a[tri(i, 0)], t[j], (i == j) ? a[tri(i, j)] + sh[i] : a[tri(i, j)]);
+        }
+#pragma unroll
+        for (int i = 1; i < n; ++i) o[tri(i, 0)] = t[i];
+        o[0] = -dinv;
+    }
+#pragma unroll
+    for (int k = 1; k < n; ++k) {
+        const double dinv = rcp(o[tri(k, k)]);
+        double t[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+            if (i != k) t[i] = o[i > k ? tri(i, k) : tri(k, i)] * dinv;
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            if (i == k) continue;
+            const double aik = o[i > k ? tri(i, k) : tri(k, i)];
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                if (j == k) continue;
+                o[tri(i, j)] = __builtin_fma(-aik, t[j], o[tri(i, j)]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+            if (i != k) o[i > k ? tri(i, k) : tri(k, i)] = t[i];
+        o[tri(k, k)] = -dinv;
+    }
+}
+
+// Solves M x = b in place of b for a packed SPD n x n matrix (LDL^T), M left untouched.
+template <int n>
+__device__ __forceinline__ void spd_solve1(const double (&m)[n * (n + 1) / 2], double (&b)[n])
+{
+    double L[n][n], W[n][n], dinv[n];
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+        double s = m[tri(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s = __builtin_fma(-W[j][k], L[j][k], s);
+        dinv[j] = rcp(s);
+#pragma unroll
+        for (int i = j + 1; i < n; ++i) {
+            double v = m[tri(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v = __builtin_fma(-W[i][k], L[j][k], v);
+            W[i][j] = v;
+            L[i][j] = v * dinv[j];
+        }
+    }
+#pragma unroll
+    for (int i = 1; i < n; ++i) {  // forward substitution, unit lower
+#pragma unroll
+        for (int k = 0; k < i; ++k) b[i] = __builtin_fma(-L[i][k], b[k], b[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < n; ++i) b[i] *= dinv[i];
+#pragma unroll
+    for (int i = n - 2; i >= 0; --i) {  // back substitution with L^T
+#pragma unroll
+        for (int k = i + 1; k < n; ++k) b[i] = __builtin_fma(-L[k][i], b[k], b[i]);
+    }
+}
+
 // Solves M x = b1 and M x = b2 for a packed SPD n x n matrix (LDL^T, two right-hand sides).
 template <int n>
 __device__ __forceinline__ void spd_solve2(const double (&m)[n * (n + 1) / 2], double (&b1)[n],

@@ -394,6 +394,10 @@ int qeif_impl(const T *uv, const T *xyz, int64_t xyz_stride, int32_t n_patterns,
     if (rc) return rc;
     if (n_patterns < 1) return fail(PNP_E_ARG, "n_patterns = %d must be >= 1", n_patterns);
     if (p && (p->max_it < 1)) return fail(PNP_E_ARG, "max_it = %d must be >= 1", p->max_it);
+    // the predict step works with 1/r_quat, 1/r_delta and 1/omega0
+    if (p && !(p->q_inv > 0.0 && p->r_quat > 0.0 && p->r_delta > 0.0 && p->omega0 > 0.0))
+        return fail(PNP_E_ARG, "q_inv = %g, r_quat = %g, r_delta = %g and omega0 = %g must all be > 0", p->q_inv,
+                    p->r_quat, p->r_delta, p->omega0);
     pnp::KinvRows ki;
     rc = kinv_rows(K, ki);
     if (rc) return rc;

@@ -370,9 +370,10 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_QEIF_WAVES) void qeif_moment_k
     QeifState st;
     qeif_init(st, p, 1.0);
     const QeifRule rule(p);
+    const QeifNoise noise(p);
     const double n = static_cast<double>(N);
     while (st.k < p.max_it) {
-        if (qeif_moment_iterate(st, M, n, p, rule, exact_ss)) break;
+        if (qeif_moment_iterate(st, M, n, p, rule, noise, exact_ss)) break;
     }
     double R[9], t[3];
     qeif_finish(st, R, t);

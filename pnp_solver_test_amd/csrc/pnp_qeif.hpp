@@ -105,10 +105,10 @@ __device__ __forceinline__ void gamma_matrix(const double (&x)[6], double (&phi)
 //
 // Recurrence (exact restatement of the information-filter loop, rearranged):
 //   Sigma_0 = I/omega0, x_0 = [1,0,0,0,0,0]
-//   each iteration:  Obar = (Sigma + R_p)^-1               (both inverses: symmetric sweeps)
+//   each iteration:  Obar = (Sigma + R_p)^-1               (taken from Omega = Sigma^-1, see QeifNoise)
 //                    Omega = Obar + q_inv * H^T H          H, r = z - h at the current x
 //                    res   = |r|                           (residual BEFORE the update)
-//                    Sigma = Omega^-1 ;  x += Sigma * (q_inv * H^T r)
+//                    Sigma = Omega^-1 ;  x += Sigma * (q_inv * H^T r)     (as a solve, Sigma not formed)
 //                    stop if |res - res_old| < rel_tol * res_old, else res_old = res
 //                    (evaluated on the squared residuals, see QeifRule)
 // The reference forms zeta = Obar x + q_inv H^T (z - h + H x) and x = Sigma zeta; since
@@ -116,7 +116,7 @@ __device__ __forceinline__ void gamma_matrix(const double (&x)[6], double (&phi)
 // Its stopping rule |(res - res_old)/res_old| < rel_tol is the same inequality (res_old > 0).
 struct QeifState {
     double x[6];    // [q(4), delta1, delta2]
-    double T[21];   // packed lower 6x6; holds -Sigma between iterations (see qeif_iterate)
+    double T[21];   // packed lower 6x6; holds the information matrix Omega between iterations
     double ss_old;  // squared residual norm of the previous iteration, in the solver's units
     double ss;      // squared residual norm at the last linearisation point, same units
     int k;          // iterations done
@@ -130,10 +130,7 @@ __device__ __forceinline__ void qeif_init(QeifState &st, const QeifParams &p, do
 #pragma unroll
     for (int i = 1; i < 6; ++i) st.x[i] = 0.0;
 #pragma unroll
-    for (int i = 0; i < 21; ++i) st.T[i] = 0.0;
-    const double s0 = -1.0 / p.omega0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) st.T[tri(i, i)] = s0;
+    for (int i = 0; i < 21; ++i) st.T[i] = 0.0;  // the first predict step sets the diagonal
     st.ss_old = p.res_old0 * p.res_old0 * unit2;
     st.ss = 1.0e10 * unit2;  // reported as a residual of 1e5 when no iteration runs
     st.k = 0;
@@ -154,47 +151,70 @@ struct QeifRule {
     }
 };
 
+// Constants of the predict step.  With Omega = Sigma^-1 in hand, (Sigma + R_p)^-1 is taken as
+//   Obar = R_p^-1 - R_p^-1 (Omega + R_p^-1)^-1 R_p^-1
+// (R_p diagonal and positive), so an iteration inverts one matrix - (Omega + R_p^-1) - and
+// solves one system - Omega dx = g - instead of inverting two.
+struct QeifNoise {
+    double sh[6];             // diagonal of R_p^-1
+    double wqq, wqd, wdd;     // products of two of its entries: (q,q), (q,delta), (delta,delta)
+    double oq, od;            // diagonal of Obar in the first iteration, 1 / (1/omega0 + r)
+    __device__ __forceinline__ explicit QeifNoise(const QeifParams &p)
+    {
+        const double rq = 1.0 / p.r_quat, rd = 1.0 / p.r_delta;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sh[i] = rq;
+        sh[4] = sh[5] = rd;
+        wqq = rq * rq;
+        wqd = rq * rd;
+        wdd = rd * rd;
+        oq = 1.0 / (1.0 / p.omega0 + p.r_quat);
+        od = 1.0 / (1.0 / p.omega0 + p.r_delta);
+    }
+};
+
 // Scalars derived from the parameters once per kernel.
 struct QeifConsts {
     double c, c_inv, dd;  // sqrt(q_inv), its reciprocal, q_inv * N
     QeifRule rule;
+    QeifNoise noise;
     __device__ __forceinline__ QeifConsts(const QeifParams &p, int N)
-        : c(sqrt(p.q_inv)), c_inv(1.0 / sqrt(p.q_inv)), dd(p.q_inv * static_cast<double>(N)), rule(p) {}
+        : c(sqrt(p.q_inv)), c_inv(1.0 / sqrt(p.q_inv)), dd(p.q_inv * static_cast<double>(N)), rule(p), noise(p) {}
 };
 
-// Predict step: T = -Sigma on entry, Obar = (Sigma + R_p)^-1 on exit.  Sigma_0 is a multiple of
-// the identity, so in the first iteration the sweep reduces to two reciprocals.
+// Predict step: T = Omega of the previous iteration on entry, Obar = (Omega^-1 + R_p)^-1 on exit.
+// Sigma_0 is a multiple of the identity, so the first iteration sets two values.
 template <bool FIRST>
-__device__ __forceinline__ void qeif_predict(QeifState &st, const QeifParams &p)
+__device__ __forceinline__ void qeif_predict(QeifState &st, const QeifNoise &nz)
 {
     double(&T)[21] = st.T;
     ++st.k;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) T[tri(i, i)] -= p.r_quat;
-    T[tri(4, 4)] -= p.r_delta;
-    T[tri(5, 5)] -= p.r_delta;
     if constexpr (FIRST) {
-        const double oq = -rcp(T[tri(0, 0)]), od = -rcp(T[tri(4, 4)]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) T[tri(i, i)] = oq;
-        T[tri(4, 4)] = od;
-        T[tri(5, 5)] = od;
+        for (int i = 0; i < 4; ++i) T[tri(i, i)] = nz.oq;
+        T[tri(4, 4)] = nz.od;
+        T[tri(5, 5)] = nz.od;
     } else {
-        sweep_neg_inverse<6>(T);
+        double Nm[21];  // -(Omega + R_p^-1)^-1
+        sweep_neg_inverse_shifted<6>(T, nz.sh, Nm);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                const double w = (i < 4) ? nz.wqq : ((j < 4) ? nz.wqd : nz.wdd);
+                T[tri(i, j)] = (i == j) ? __builtin_fma(Nm[tri(i, j)], w, nz.sh[i]) : Nm[tri(i, j)] * w;
+            }
+        }
     }
 }
 
-// Correct step: T = Omega on entry and -Sigma on exit; x += Sigma g; returns true when the
-// stopping rule fires on the squared residual ss of the linearisation point just used.
-__device__ __forceinline__ bool qeif_correct(QeifState &st, const double (&g)[6], double ss, const QeifRule &rule)
+// Correct step: T = Omega on entry and on exit; x += Omega^-1 g; returns true when the stopping
+// rule fires on the squared residual ss of the linearisation point just used.
+__device__ __forceinline__ bool qeif_correct(QeifState &st, double (&g)[6], double ss, const QeifRule &rule)
 {
-    double(&T)[21] = st.T;
-    sweep_neg_inverse<6>(T);
+    spd_solve1<6>(st.T, g);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) st.x[i] = __builtin_fma(-T[i >= j ? tri(i, j) : tri(j, i)], g[j], st.x[i]);
-    }
+    for (int i = 0; i < 6; ++i) st.x[i] += g[i];
     const bool stop = (ss > rule.lo2 * st.ss_old) && (ss < rule.hi2 * st.ss_old);
     st.ss = ss;
     st.ss_old = ss;
@@ -207,8 +227,7 @@ __device__ __forceinline__ double qeif_residual(const QeifState &st, double unit
     return sqrt_pos(st.ss) * unit_inv;
 }
 
-// One iteration; returns true when the stopping rule fires.  T is swept twice and changes
-// sign each time: -Sigma on entry, Obar after the first sweep, -Sigma again on exit.
+// One iteration; returns true when the stopping rule fires.
 // FIRST: the iteration that starts from the state qeif_init leaves (x = [1,0,0,0,0,0], Sigma a
 // multiple of the identity), for which the predict step and the point terms simplify.
 template <int LPI, int NCT, bool FIRST, typename PointFetch>
@@ -218,7 +237,7 @@ __device__ __forceinline__ bool qeif_iterate(QeifState &st, const PointFetch &pt
     double(&x)[6] = st.x;
     double(&T)[21] = st.T;
     const double c = kc.c;
-    qeif_predict<FIRST>(st, p);
+    qeif_predict<FIRST>(st, kc.noise);
     // update: Omega = Obar + q_inv H^T H, accumulated point by point
     const double qs[4] = {2.0 * c * x[0], 2.0 * c * x[1], 2.0 * c * x[2], 2.0 * c * x[3]};
     const double hq[4] = {0.5 * x[0], 0.5 * x[1], 0.5 * x[2], 0.5 * x[3]};
@@ -444,14 +463,14 @@ __device__ __forceinline__ void moment_axis_terms(const double (&S0)[6], const d
 template <typename ExactResidual>
 __device__ __forceinline__ bool qeif_moment_iterate(QeifState &st, const Moments &M, double n,
                                                     const QeifParams &p, const QeifRule &rule,
-                                                    const ExactResidual &exact_ss)
+                                                    const QeifNoise &nz, const ExactResidual &exact_ss)
 {
     double(&x)[6] = st.x;
     double(&T)[21] = st.T;
     if (st.k == 0)  // Obar
-        qeif_predict<true>(st, p);
+        qeif_predict<true>(st, nz);
     else
-        qeif_predict<false>(st, p);
+        qeif_predict<false>(st, nz);
 
     double phi[9], gamma;
     gamma_matrix(x, phi, gamma);
@@ -481,7 +500,7 @@ __device__ __forceinline__ bool qeif_moment_iterate(QeifState &st, const Moments
     }
     T[tri(4, 4)] = __builtin_fma(w, n, T[tri(4, 4)]);
     T[tri(5, 5)] = __builtin_fma(w, n, T[tri(5, 5)]);
-    const double g[6] = {w * (gax[0] + gay[0]), w * (gax[1] + gay[1]), w * (gax[2] + gay[2]),
+    double g[6] = {w * (gax[0] + gay[0]), w * (gax[1] + gay[1]), w * (gax[2] + gay[2]),
                          w * (gax[3] + gay[3]), w * gdx, w * gdy};
     return qeif_correct(st, g, ss, rule);
 }

@@ -180,6 +180,24 @@ def test_qeif_custom_params_fixed_five_iterations(golden, torch_dev):
     assert_tight(out2, ref2)
 
 
+@pytest.mark.parametrize("r_quat,r_delta", [(1e-4, 1e-5), (1e-7, 1e-7), (10.0, 1.0), (1e3, 1e-6)])
+def test_qeif_process_noise_range(golden, torch_dev, r_quat, r_delta):
+    """The kernel takes (Sigma + R_p)^-1 as R_p^-1 - R_p^-1 (Omega + R_p^-1)^-1 R_p^-1, a difference
+    that cancels more the smaller R_p is; the oracle inverts Sigma + R_p literally.  Same poses
+    and iteration counts from R_p six orders below the reference's constants to four above
+    (float64 flavour, so that the comparison sees the algebra and not the output rounding)."""
+    g, uv = stress_uv6(golden)
+    uv = uv[:4000].astype(np.float64)
+    P = P6f.astype(np.float64)
+    out = pnp.solve_pnp_batch(uv, P, K, params=pnp.make_params(r_quat=r_quat, r_delta=r_delta))
+    ref = c_oracle.qeif_batch(uv, P, K, r_quat=r_quat, r_delta=r_delta)
+    assert out["R"].dtype == np.float64
+    assert (out["iters"] == ref["iters"]).mean() >= 0.999
+    same = out["iters"] == ref["iters"]
+    assert np.abs(out["R"] - ref["R"])[same].max() <= 1e-8
+    assert rel_t(out["t"][same], ref["t"][same]).max() <= 1e-8
+
+
 def test_multi_pattern_selection(golden, torch_dev):
     g = golden("multi_pattern")
     pats = g["xyz"].astype(np.float32)

@@ -57,6 +57,10 @@ def test_argument_errors_come_back_as_codes_with_messages():
     singular = _lib.k_array(np.zeros((3, 3)))
     assert lib.pnp_qeif_batch_f32(a, a, 0, singular, 1, 6, None, a, a, None, None, None, 0, None) == -1
     assert b"singular" in lib.pnp_last_error()
+    for bad in (dict(r_quat=0.0), dict(r_delta=-1.0), dict(omega0=0.0), dict(q_inv=float("nan")), dict(max_it=0)):
+        prm = pnp.make_params(**bad)
+        assert lib.pnp_qeif_batch_f32(a, a, 0, Kc, 1, 6, ctypes.byref(prm), a, a, None, None, None, 0, None) == -1, bad
+        assert b"must" in lib.pnp_last_error()
     assert lib.pnp_set_lanes_per_problem(3) == -1
     assert lib.pnp_set_lanes_per_problem(0) == 0
     # the float64 flavour, the generator, the comparison epilogue and the form switch check alike
