@@ -306,8 +306,8 @@ def main():
             other = {}
             n_small = max(5, min(50, args.steps // 2))
             # every variant gets its own spin-up: the host work between two variants leaves the GPU
-            # idle long enough for its clock to drop, and the first ~20 ms of launches run slow
-            n_spin = 100
+            # idle long enough for its clock to drop, and the first ~30 ms of launches run slow
+            n_spin = 200
             P6 = torch.from_numpy(synth.PATTERN6.astype(np.float32)).to(dev)
             ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, P6, K, want_rpy=False), n_small, n_spin)
             other["qeif_n6_shared_pattern"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4),
