@@ -39,6 +39,10 @@ struct PassBounds {  // pass criteria of the comparison epilogue: depth [cm], ro
 struct QeifParams {
     double q_inv, r_quat, r_delta, omega0, rel_tol, res_old0;
     int max_it;
+    // derived on the host once per call (divisions and square roots the kernels would otherwise
+    // repeat in every lane): sqrt(q_inv) and its reciprocal; 1/r_quat, 1/r_delta; the diagonal of
+    // the first predicted information matrix, 1/(1/omega0 + r); the stopping-rule bounds
+    double c, c_inv, rq_inv, rd_inv, oq, od, lo2, hi2;
 };
 
 // ------------------------------------------------------------------------------------------

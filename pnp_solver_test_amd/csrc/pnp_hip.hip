@@ -164,6 +164,18 @@ pnp::QeifParams to_device_params(const pnp_qeif_params *p)
     q.rel_tol = d.rel_tol;
     q.res_old0 = d.res_old0;
     q.max_it = d.max_it;
+    q.c = sqrt(d.q_inv);
+    q.c_inv = 1.0 / q.c;
+    q.rq_inv = 1.0 / d.r_quat;
+    q.rd_inv = 1.0 / d.r_delta;
+    q.oq = 1.0 / (1.0 / d.omega0 + d.r_quat);
+    q.od = 1.0 / (1.0 / d.omega0 + d.r_delta);
+    // |res - res_old| < tol res_old on squared residuals: lo2 ss_old < ss < hi2 ss_old.  A bound
+    // whose factor is not positive is always (lower) or never (upper) met for res_old > 0, which
+    // the negative stand-ins reproduce; res_old = 0 and NaN never stop, as in the original form.
+    const double lo = 1.0 - d.rel_tol, hi = 1.0 + d.rel_tol;
+    q.lo2 = lo > 0.0 ? lo * lo : (lo < 0.0 ? -1.0 : 0.0);
+    q.hi2 = hi > 0.0 ? hi * hi : -1.0;
     return q;
 }
 

@@ -65,6 +65,8 @@ __device__ __forceinline__ void jacobi_rotate(double (&S)[3][3], double (&V)[3][
 {
     const double apq = S[p][q];
     if (apq == 0.0) return;
+    // (IEEE division and square root here: apq decays to subnormal values and theta overflows,
+    // outside the range of the refined hardware seeds)
     const double theta = (S[q][q] - S[p][p]) / (2.0 * apq);
     const double tt = ((theta >= 0.0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
     const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
@@ -194,8 +196,8 @@ __device__ __forceinline__ void lm12_solve(const PointFetch &pts, int N, double 
             const double v5[6] = {u1[0], u1[1], u1[2], -u2[0], -u2[1], -u2[2]};
             lm12_row<6>(A, b, c12, v5, -(d11 - d22));
             constexpr int ca[3] = {0, 1, 2}, cb[3] = {3, 4, 5}, cc[3] = {6, 7, 8};
-            const double n1 = sqrt(d11), n2 = sqrt(d22), n3 = sqrt(d33);
-            const double h1 = 0.5 / n1, h2 = 0.5 / n2, h3 = 0.5 / n3;
+            const double n1 = sqrt_pos(d11), n2 = sqrt_pos(d22), n3 = sqrt_pos(d33);
+            const double h1 = 0.5 * rcp(n1), h2 = 0.5 * rcp(n2), h3 = 0.5 * rcp(n3);
             const double v6[3] = {u1[0] * h1, u1[1] * h1, u1[2] * h1};
             lm12_row<3>(A, b, ca, v6, 1.0 - n1);
             const double v7[3] = {u2[0] * h2, u2[1] * h2, u2[2] * h2};
@@ -205,7 +207,7 @@ __device__ __forceinline__ void lm12_solve(const PointFetch &pts, int N, double 
         }
 #pragma unroll
         for (int i = 0; i < 12; ++i) A[tri(i, i)] += lam;
-        res = sqrt(ss);
+        res = sqrt_pos(ss);
         ldlt_solve_inplace<12>(A, b);
 #pragma unroll
         for (int i = 0; i < 12; ++i) x[i] += b[i];

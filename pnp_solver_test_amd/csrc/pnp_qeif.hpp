@@ -138,17 +138,10 @@ __device__ __forceinline__ void qeif_init(QeifState &st, const QeifParams &p, do
 
 // The stopping rule |res - res_old| < rel_tol res_old on squared residuals (no square root in
 // the loop): with res, res_old >= 0 it reads (1 - tol) res_old < res < (1 + tol) res_old, i.e.
-// lo2 ss_old < ss < hi2 ss_old.  A bound whose factor is not positive is always (lower) or
-// never (upper) met for res_old > 0, which the negative stand-ins below reproduce; res_old = 0
-// and NaN never stop, as in the original form.
+// lo2 ss_old < ss < hi2 ss_old, the bounds prepared on the host (QeifParams).
 struct QeifRule {
     double lo2, hi2;
-    __device__ __forceinline__ explicit QeifRule(const QeifParams &p)
-    {
-        const double lo = 1.0 - p.rel_tol, hi = 1.0 + p.rel_tol;
-        lo2 = lo > 0.0 ? lo * lo : (lo < 0.0 ? -1.0 : 0.0);
-        hi2 = hi > 0.0 ? hi * hi : -1.0;
-    }
+    __device__ __forceinline__ explicit QeifRule(const QeifParams &p) : lo2(p.lo2), hi2(p.hi2) {}
 };
 
 // Constants of the predict step.  With Omega = Sigma^-1 in hand, (Sigma + R_p)^-1 is taken as
@@ -161,15 +154,15 @@ struct QeifNoise {
     double oq, od;            // diagonal of Obar in the first iteration, 1 / (1/omega0 + r)
     __device__ __forceinline__ explicit QeifNoise(const QeifParams &p)
     {
-        const double rq = 1.0 / p.r_quat, rd = 1.0 / p.r_delta;
+        const double rq = p.rq_inv, rd = p.rd_inv;
 #pragma unroll
         for (int i = 0; i < 4; ++i) sh[i] = rq;
         sh[4] = sh[5] = rd;
         wqq = rq * rq;
         wqd = rq * rd;
         wdd = rd * rd;
-        oq = 1.0 / (1.0 / p.omega0 + p.r_quat);
-        od = 1.0 / (1.0 / p.omega0 + p.r_delta);
+        oq = p.oq;
+        od = p.od;
     }
 };
 
@@ -179,7 +172,7 @@ struct QeifConsts {
     QeifRule rule;
     QeifNoise noise;
     __device__ __forceinline__ QeifConsts(const QeifParams &p, int N)
-        : c(sqrt(p.q_inv)), c_inv(1.0 / sqrt(p.q_inv)), dd(p.q_inv * static_cast<double>(N)), rule(p), noise(p) {}
+        : c(p.c), c_inv(p.c_inv), dd(p.q_inv * static_cast<double>(N)), rule(p), noise(p) {}
 };
 
 // Predict step: T = Omega of the previous iteration on entry, Obar = (Omega^-1 + R_p)^-1 on exit.
@@ -291,7 +284,7 @@ __device__ __forceinline__ void qeif_finish(const QeifState &st, double (&R)[9],
 {
     double phi[9], gamma;
     gamma_matrix(st.x, phi, gamma);
-    const double t3 = 1.0 / gamma;
+    const double t3 = rcp(gamma);
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = phi[i] * t3;
     t[0] = st.x[4] * t3;
