@@ -76,17 +76,19 @@ __device__ __forceinline__ double sqrt_pos(double x)
 
 __device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // i >= j
 
-// In-place symmetric sweep of every pivot: a <- -(a^-1) for a symmetric definite n x n
-// matrix held as its packed lower triangle (a[tri(i,j)], i >= j).  Sweeping pivot k maps
+// Symmetric sweep: sweeping every pivot of a symmetric definite n x n matrix held as its packed
+// lower triangle (a[tri(i,j)], i >= j) leaves -(a^-1).  Sweeping pivot k maps
 //   a_kk -> -1/a_kk,  a_ik -> a_ik/a_kk,  a_ij -> a_ij - a_ik a_jk / a_kk   (i, j != k)
-// which keeps the matrix symmetric at every step, so the whole inversion runs in the 21
-// registers of the packed triangle plus one column of temporaries.  Works for positive and
-// for negative definite input alike (no pivoting is needed in either case).
-template <int n>
-__device__ __forceinline__ void sweep_neg_inverse(double (&a)[n * (n + 1) / 2])
+// which keeps the matrix symmetric at every step, so the whole inversion runs in the registers
+// of the packed triangle plus one column of temporaries.  Works for positive and for negative
+// definite input alike (no pivoting is needed in either case).
+//
+// sweep_pivots<n, K0> sweeps pivots K0 .. n-1 in place.
+template <int n, int K0>
+__device__ __forceinline__ void sweep_pivots(double (&a)[n * (n + 1) / 2])
 {
 #pragma unroll
-    for (int k = 0; k < n; ++k) {
+    for (int k = K0; k < n; ++k) {
         const double dinv = rcp(a[tri(k, k)]);
         double t[n];
 #pragma unroll
@@ -109,50 +111,26 @@ __device__ __forceinline__ void sweep_neg_inverse(double (&a)[n * (n + 1) / 2])
     }
 }
 
-// o <- -((a + diag(sh))^-1) for a symmetric definite n x n matrix, a left untouched: the first
-// pivot is swept out of place (reading a, writing o), the others in place on o, so that keeping
-// a costs no register copies.
+// o <- -((a + diag(sh))^-1), a left untouched: the first pivot is swept out of place (reading a,
+// writing o), the others in place on o, so that keeping a costs no register copies.
 template <int n>
 __device__ __forceinline__ void sweep_neg_inverse_shifted(const double (&a)[n * (n + 1) / 2],
                                                           const double (&sh)[n], double (&o)[n * (n + 1) / 2])
 {
-    {
-        const double dinv = rcp(a[0] + sh[0]);
-        double t[n];
+    const double dinv = rcp(a[0] + sh[0]);
+    double t[n];
 #pragma unroll
-        for (int i = 1; i < n; ++i) t[i] = a[tri(i, 0)] * dinv;
+    for (int i = 1; i < n; ++i) t[i] = a[tri(i, 0)] * dinv;
 #pragma unroll
-        for (int i = 1; i < n; ++i) {
+    for (int i = 1; i < n; ++i) {
 #pragma unroll
-            for (int j = 1; j <= i; ++j)
-                o[tri(i, j)] = __builtin_fma(-a[tri(i, 0)], t[j], (i == j) ? a[tri(i, j)] + sh[i] : a[tri(i, j)]);
-        }
-#pragma unroll
-        for (int i = 1; i < n; ++i) o[tri(i, 0)] = t[i];
-        o[0] = -dinv;
+        for (int j = 1; j <= i; ++j)
+            o[tri(i, j)] = __builtin_fma(-a[tri(i, 0)], t[j], (i == j) ? a[tri(i, j)] + sh[i] : a[tri(i, j)]);
     }
 #pragma unroll
-    for (int k = 1; k < n; ++k) {
-        const double dinv = rcp(o[tri(k, k)]);
-        double t[n];
-#pragma unroll
-        for (int i = 0; i < n; ++i)
-            if (i != k) t[i] = o[i > k ? tri(i, k) : tri(k, i)] * dinv;
-#pragma unroll
-        for (int i = 0; i < n; ++i) {
-            if (i == k) continue;
-            const double aik = o[i > k ? tri(i, k) : tri(k, i)];
-#pragma unroll
-            for (int j = 0; j <= i; ++j) {
-                if (j == k) continue;
-                o[tri(i, j)] = __builtin_fma(-aik, t[j], o[tri(i, j)]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < n; ++i)
-            if (i != k) o[i > k ? tri(i, k) : tri(k, i)] = t[i];
-        o[tri(k, k)] = -dinv;
-    }
+    for (int i = 1; i < n; ++i) o[tri(i, 0)] = t[i];
+    o[0] = -dinv;
+    sweep_pivots<n, 1>(o);
 }
 
 // Solves M x = b in place of b for a packed SPD n x n matrix (LDL^T), M left untouched.
