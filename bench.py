@@ -58,10 +58,10 @@ def qeif_flops(n_points, iters_mean):
 
 
 def qeif_moment_flops(n_points, iters_mean):
-    """float64 flops (fma = 2) per solve of the moment form: 58 fused ops per point once, then
-    per iteration ~700 for H^T H, H^T r and |r|^2 from the 50 sums, two 6x6 sweeps and ~60 for
-    the update and the stopping rule."""
-    return 2.0 * (58.0 * n_points + iters_mean * (700.0 + 2 * 150.0 + 60.0))
+    """float64 flops (fma = 2) per solve of the moment form: 49 fused ops per point once, then
+    per iteration ~650 for H^T H, H^T r and |r|^2 from the 40 sums, and ~280 for the predict
+    sweep, the LDL^T solve, the update and the stopping rule."""
+    return 2.0 * (49.0 * n_points + iters_mean * (650.0 + 280.0))
 
 
 def dlt_flops(n_points, num_it=3):

@@ -325,51 +325,48 @@ __device__ __forceinline__ void qeif_solve(const PointFetch &pts, int N, int lan
 //   sum r     = b1 - m0.phia + m1.phi3 - n d
 //   sum r^2   = (b2 + 2 m2.phi3 + phi3^T S2 phi3) - 2 (m1.phia + d b1 + phi3^T S1 phia + d m1.phi3)
 //               + (phia^T S0 phia + 2 d m0.phia + n d^2)
-// (Qa, phia = Q1, phi1 for the x rows and Q2, phi2 for the y rows).  The 50 sums are formed
-// once per problem; an iteration then costs about 700 fused operations whatever N is, against
-// 78 N for the point-by-point form, which pays from N of about 16 upwards.
+// (Qa, phia = Q1, phi1 for the x rows and Q2, phi2 for the y rows).  S2, m2 and b2 meet only Q3
+// and phi3, which the axes share, so they are kept summed over the axes: 40 sums in all, formed
+// once per problem; an iteration then costs about 650 fused operations whatever N is, against
+// 70 N for the point-by-point form.
 //
-// sum r^2 is a difference of large terms: its rounding noise is about 2e-15 (b2x + b2y).  When
-// it comes out below kMomentResidualFloor (b2x + b2y) the residual is recomputed point by point
+// sum r^2 is a difference of large terms: its rounding noise is about 2e-15 b2.  When
+// it comes out below kMomentResidualFloor b2 the residual is recomputed point by point
 // from global memory, so the 1 % stopping rule always sees a residual good to 1e-6 or better.
 // On pixel-quantised or noisy input that branch is never taken.
 
 constexpr double kMomentResidualFloor = 1e-8;
 
 struct AxisMoments {
-    double S1[6], S2[6], m1[3], m2[3], b1, b2;  // S*: packed lower 3x3
+    double S1[6], m1[3], b1;  // sum b p p^T (packed lower 3x3), sum b p, sum b
 };
 
+// The second-order sums (b^2 p p^T, b^2 p, b^2) enter H^T H, H^T r and |r|^2 only through Q3 and
+// phi3, which both axes share, so only their sum over the two axes is kept: S2 = sum (bx^2 +
+// by^2) p p^T, and likewise m2 and b2.
 struct Moments {
     double S0[6], m0[3];
     AxisMoments ax, ay;
+    double S2[6], m2[3], b2;
 };
 
 __device__ __forceinline__ void moments_clear(Moments &M)
 {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) M.S0[i] = M.ax.S1[i] = M.ax.S2[i] = M.ay.S1[i] = M.ay.S2[i] = 0.0;
+    for (int i = 0; i < 6; ++i) M.S0[i] = M.ax.S1[i] = M.ay.S1[i] = M.S2[i] = 0.0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) M.m0[i] = M.ax.m1[i] = M.ax.m2[i] = M.ay.m1[i] = M.ay.m2[i] = 0.0;
-    M.ax.b1 = M.ax.b2 = M.ay.b1 = M.ay.b2 = 0.0;
+    for (int i = 0; i < 3; ++i) M.m0[i] = M.ax.m1[i] = M.ay.m1[i] = M.m2[i] = 0.0;
+    M.ax.b1 = M.ay.b1 = M.b2 = 0.0;
 }
 
 __device__ __forceinline__ void axis_moments_add(AxisMoments &A, const double (&pp)[6], const double (&pt)[3],
                                                  double b)
 {
-    const double bb = b * b;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        A.S1[i] = __builtin_fma(b, pp[i], A.S1[i]);
-        A.S2[i] = __builtin_fma(bb, pp[i], A.S2[i]);
-    }
+    for (int i = 0; i < 6; ++i) A.S1[i] = __builtin_fma(b, pp[i], A.S1[i]);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        A.m1[i] = __builtin_fma(b, pt[i], A.m1[i]);
-        A.m2[i] = __builtin_fma(bb, pt[i], A.m2[i]);
-    }
+    for (int i = 0; i < 3; ++i) A.m1[i] = __builtin_fma(b, pt[i], A.m1[i]);
     A.b1 += b;
-    A.b2 += bb;
 }
 
 // The pixel-dependent sums only; pp = packed lower p p^T, pt = p.
@@ -378,6 +375,12 @@ __device__ __forceinline__ void moments_add_axes(Moments &M, const double (&pp)[
 {
     axis_moments_add(M.ax, pp, pt, bx);
     axis_moments_add(M.ay, pp, pt, by);
+    const double bb = __builtin_fma(bx, bx, by * by);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) M.S2[i] = __builtin_fma(bb, pp[i], M.S2[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) M.m2[i] = __builtin_fma(bb, pt[i], M.m2[i]);
+    M.b2 += bb;
 }
 
 __device__ __forceinline__ void moments_add(Moments &M, double X, double Y, double Z, double bx, double by)
@@ -388,8 +391,7 @@ __device__ __forceinline__ void moments_add(Moments &M, double X, double Y, doub
     for (int i = 0; i < 6; ++i) M.S0[i] += pp[i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) M.m0[i] += pt[i];
-    axis_moments_add(M.ax, pp, pt, bx);
-    axis_moments_add(M.ay, pp, pt, by);
+    moments_add_axes(M, pp, pt, bx, by);
 }
 
 // y = S v for a packed symmetric 3x3
@@ -405,7 +407,8 @@ __device__ __forceinline__ double dot3(const double (&a)[3], const double (&b)[3
     return __builtin_fma(a[0], b[0], __builtin_fma(a[1], b[1], a[2] * b[2]));
 }
 
-// One axis' share of H^T H (AA: packed lower 4x4, accumulated), sum a, sum a r, sum r, sum r^2.
+// One axis' share of H^T H (AA: packed lower 4x4, accumulated), sum a, sum a r, sum r, sum r^2,
+// without the terms in S2, m2 and b2 (added once for both axes by the caller).
 // Qa and Q3 are 3x4 (derivatives of phia, phi3 with respect to q).
 __device__ __forceinline__ void moment_axis_terms(const double (&S0)[6], const double (&m0)[3], double n,
                                                   const AxisMoments &A, const double (&Qa)[3][4],
@@ -413,42 +416,38 @@ __device__ __forceinline__ void moment_axis_terms(const double (&S0)[6], const d
                                                   const double (&phi3)[3], double d, double (&AA)[10],
                                                   double (&sa)[4], double (&ga)[4], double &gd, double &rr)
 {
-    double s0a[3], s1a[3], s13[3], s23[3], w1[3], w2[3];
+    double s0a[3], s1a[3], s13[3], w1[3], w2[3];
     sym3_mul(S0, phia, s0a);
     sym3_mul(A.S1, phia, s1a);
     sym3_mul(A.S1, phi3, s13);
-    sym3_mul(A.S2, phi3, s23);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         w1[k] = __builtin_fma(-d, m0[k], (A.m1[k] - s0a[k]) + s13[k]);
-        w2[k] = __builtin_fma(-d, A.m1[k], (A.m2[k] - s1a[k]) + s23[k]);
+        w2[k] = __builtin_fma(-d, A.m1[k], -s1a[k]);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const double qa[3] = {Qa[0][j], Qa[1][j], Qa[2][j]};
         const double q3[3] = {Q3[0][j], Q3[1][j], Q3[2][j]};
-        double u0[3], u1[3], v0[3], v1[3];
+        double u0[3], u1[3], v0[3];
         sym3_mul(S0, qa, u0);
         sym3_mul(A.S1, q3, u1);
         sym3_mul(A.S1, qa, v0);
-        sym3_mul(A.S2, q3, v1);
         const double U[3] = {u0[0] - u1[0], u0[1] - u1[1], u0[2] - u1[2]};
-        const double V[3] = {v0[0] - v1[0], v0[1] - v1[1], v0[2] - v1[2]};
 #pragma unroll
         for (int i = j; i < 4; ++i) {
             const double qi[3] = {Qa[0][i], Qa[1][i], Qa[2][i]};
             const double ri[3] = {Q3[0][i], Q3[1][i], Q3[2][i]};
-            AA[tri(i, j)] += dot3(qi, U) - dot3(ri, V);
+            AA[tri(i, j)] += dot3(qi, U) - dot3(ri, v0);
         }
         sa[j] = dot3(qa, m0) - dot3(q3, A.m1);
         ga[j] = dot3(qa, w1) - dot3(q3, w2);
     }
     const double m1p3 = dot3(A.m1, phi3), m0pa = dot3(m0, phia);
     gd = __builtin_fma(-n, d, (A.b1 - m0pa) + m1p3);
-    const double t_bb = __builtin_fma(2.0, dot3(A.m2, phi3), A.b2) + dot3(phi3, s23);
     const double t_bf = __builtin_fma(d, A.b1 + m1p3, dot3(A.m1, phia)) + dot3(phi3, s1a);
     const double t_ff = __builtin_fma(d, __builtin_fma(n, d, 2.0 * m0pa), dot3(phia, s0a));
-    rr = __builtin_fma(-2.0, t_bf, t_bb) + t_ff;
+    rr = __builtin_fma(-2.0, t_bf, t_ff);
 }
 
 // One iteration from the moments; same state and recurrence as qeif_iterate.  exact_ss()
@@ -479,8 +478,25 @@ __device__ __forceinline__ bool qeif_moment_iterate(QeifState &st, const Moments
     for (int i = 0; i < 10; ++i) AA[i] = 0.0;
     moment_axis_terms(M.S0, M.m0, n, M.ax, Q1, Q3, phi1, phi3, x[4], AA, sax, gax, gdx, rrx);
     moment_axis_terms(M.S0, M.m0, n, M.ay, Q2, Q3, phi2, phi3, x[5], AA, say, gay, gdy, rry);
-    double ss = rrx + rry;
-    if (!(ss >= kMomentResidualFloor * (M.ax.b2 + M.ay.b2))) ss = exact_ss(x);
+    // the second-order terms, once for both axes: Q3^T S2 Q3 into H^T H, -Q3^T (m2 + S2 phi3) into
+    // the gradient, b2 + 2 m2.phi3 + phi3^T S2 phi3 into |r|^2
+    double s23[3], gq[4];
+    sym3_mul(M.S2, phi3, s23);
+    const double wc[3] = {M.m2[0] + s23[0], M.m2[1] + s23[1], M.m2[2] + s23[2]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double q3[3] = {Q3[0][j], Q3[1][j], Q3[2][j]};
+        double y[3];
+        sym3_mul(M.S2, q3, y);
+#pragma unroll
+        for (int i = j; i < 4; ++i) {
+            const double ri[3] = {Q3[0][i], Q3[1][i], Q3[2][i]};
+            AA[tri(i, j)] += dot3(ri, y);
+        }
+        gq[j] = (gax[j] + gay[j]) - dot3(q3, wc);
+    }
+    double ss = (rrx + rry) + (__builtin_fma(2.0, dot3(M.m2, phi3), M.b2) + dot3(phi3, s23));
+    if (!(ss >= kMomentResidualFloor * M.b2)) ss = exact_ss(x);
 
     // Omega = Obar + q_inv H^T H
     const double w = p.q_inv;
@@ -493,8 +509,7 @@ __device__ __forceinline__ bool qeif_moment_iterate(QeifState &st, const Moments
     }
     T[tri(4, 4)] = __builtin_fma(w, n, T[tri(4, 4)]);
     T[tri(5, 5)] = __builtin_fma(w, n, T[tri(5, 5)]);
-    double g[6] = {w * (gax[0] + gay[0]), w * (gax[1] + gay[1]), w * (gax[2] + gay[2]),
-                         w * (gax[3] + gay[3]), w * gdx, w * gdy};
+    double g[6] = {w * gq[0], w * gq[1], w * gq[2], w * gq[3], w * gdx, w * gdy};
     return qeif_correct(st, g, ss, rule);
 }
 
