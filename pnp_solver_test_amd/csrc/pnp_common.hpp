@@ -211,6 +211,15 @@ __device__ __forceinline__ void spd_solve2(const double (&m)[n * (n + 1) / 2], d
     }
 }
 
+// Marks a value that is equal in every lane of the wavefront as such, so that it can live in
+// scalar registers.
+__device__ __forceinline__ double wave_uniform(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 // Sum of v over the LPI lanes of a problem (xor butterfly); every lane gets the total.
 template <int LPI>
 __device__ __forceinline__ double group_sum(double v)

@@ -255,9 +255,9 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_QEIF_WAVES) void qeif_moment_k
 #pragma unroll
             for (int k = 0; k < 9; ++k) part[k] += s_pat[9 * i + k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) M.m0[k] = group_sum<64>(part[k]);
+        for (int k = 0; k < 3; ++k) M.m0[k] = wave_uniform(group_sum<64>(part[k]));
 #pragma unroll
-        for (int k = 0; k < 6; ++k) M.S0[k] = group_sum<64>(part[3 + k]);
+        for (int k = 0; k < 6; ++k) M.S0[k] = wave_uniform(group_sum<64>(part[3 + k]));
     }
 
     // A chunk holds, per problem, a run of 2C pixel elements and a run of 3C pattern elements.
