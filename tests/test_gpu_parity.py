@@ -941,6 +941,22 @@ def test_moment_form_n68_against_reference(golden, torch_dev, moment_form):
     assert np.array_equal(host["R"], f32["R"]) and np.array_equal(host["rpy_deg"], f32["rpy_deg"])
 
 
+@pytest.mark.parametrize("r_quat,r_delta", [(1e-4, 1e-5), (1e-7, 1e-7), (10.0, 1.0), (1e3, 1e-6)])
+def test_moment_form_process_noise_range(golden, torch_dev, moment_form, r_quat, r_delta):
+    """The predict step's difference form (see test_qeif_process_noise_range) in the moment
+    kernel, both pattern layouts, against the literal oracle."""
+    g = golden("qeif_n68")
+    uv, P = g["uv"].astype(np.float64), g["xyz"].astype(np.float64)
+    prm = pnp.make_params(r_quat=r_quat, r_delta=r_delta)
+    ref = c_oracle.qeif_batch(uv, P, K, r_quat=r_quat, r_delta=r_delta)
+    for xyz in (P, np.broadcast_to(P, (len(uv),) + P.shape)):
+        out = solve_dev64(uv, xyz, torch_dev, params=prm)
+        same = out["iters"] == ref["iters"]
+        assert same.mean() >= 0.995
+        assert np.abs(out["R"] - ref["R"])[same].max() <= 1e-8
+        assert rel_t(out["t"][same], ref["t"][same]).max() <= 1e-8
+
+
 def test_moment_form_equals_point_form(golden, torch_dev):
     """Same problems through both forms: 15 points (two staging chunks, the second partial),
     ragged batch sizes, shared and per-problem patterns."""
