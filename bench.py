@@ -241,6 +241,18 @@ def main():
                       ms_per_step=round(float(gmax.item()) / g_steps * 1e3, 4),
                       gathered_bytes_per_rank_per_step=int(full["R"].numel() * 4 + full["t"].numel() * 4),
                       what="solve + all_gather_into_tensor of R and t (RCCL)")
+        # the same with the poses collected on rank 0 only
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(g_steps):
+            o = step()
+            pnp.gather_results({"R": o["R"], "t": o["t"]}, dst=0)
+        barrier()
+        gmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(gmax, op=dist.ReduceOp.MAX)
+        gather["to_rank_0_only"] = dict(solves_per_s=round(world * B * g_steps / float(gmax.item()), 1),
+                                        ms_per_step=round(float(gmax.item()) / g_steps * 1e3, 4),
+                                        what="solve + gather of R and t to rank 0 (RCCL)")
 
     if rank == 0:
         total = world * B * args.steps

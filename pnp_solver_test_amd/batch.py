@@ -233,15 +233,19 @@ def shard_bounds(total: int, rank: int, world_size: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_results(local: dict, group=None) -> dict:
-    """Optional collective after a sharded solve: all-gather every rank's result arrays (torch
-    tensors) in rank order.  Slices may differ in length (shard_bounds hands out sizes that
-    differ by one): shorter ones are padded for the collective and trimmed afterwards.  Uses
-    torch.distributed, i.e. RCCL over xGMI for HIP tensors and gloo for CPU tensors."""
+def gather_results(local: dict, group=None, dst=None):
+    """Optional collective after a sharded solve: every rank's result arrays (torch tensors) in
+    rank order, on every rank (all-gather, the default) or on rank `dst` only (gather; the other
+    ranks get None).  Gathering to one rank moves world-1 slices over world-1 different xGMI
+    links at once instead of world-1 slices into every rank.  Slices may differ in length
+    (shard_bounds hands out sizes that differ by one): shorter ones are padded for the collective
+    and trimmed afterwards.  Uses torch.distributed, i.e. RCCL over xGMI for HIP tensors and gloo
+    for CPU tensors."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     first = next(iter(local.values()))
     n_local = torch.tensor([first.shape[0]], dtype=torch.int64, device=first.device)
     counts = torch.empty(world, dtype=torch.int64, device=first.device)
@@ -254,13 +258,24 @@ def gather_results(local: dict, group=None) -> dict:
         if val.shape[0] < n_max:
             pad = torch.zeros((n_max - val.shape[0],) + tuple(val.shape[1:]), dtype=val.dtype, device=val.device)
             val = torch.cat([val, pad], dim=0)
-        buf = torch.empty((world * n_max,) + tuple(val.shape[1:]), dtype=val.dtype, device=val.device)
-        dist.all_gather_into_tensor(buf, val, group=group)
+        if dst is None:
+            buf = torch.empty((world * n_max,) + tuple(val.shape[1:]), dtype=val.dtype, device=val.device)
+            dist.all_gather_into_tensor(buf, val, group=group)
+        else:
+            buf = None
+            parts = None
+            if rank == dst:
+                buf = torch.empty((world * n_max,) + tuple(val.shape[1:]), dtype=val.dtype, device=val.device)
+                parts = list(buf.chunk(world, dim=0))
+            dist.gather(val, gather_list=parts, dst=dist.get_global_rank(group, dst) if group is not None else dst,
+                        group=group)
+            if rank != dst:
+                continue
         if min(counts) == n_max:
             out[key] = buf
         else:
             out[key] = torch.cat([buf[r * n_max:r * n_max + counts[r]] for r in range(world)], dim=0)
-    return out
+    return out if (dst is None or rank == dst) else None
 
 
 def project_batch(roll, yaw, pitch, t, xyz, K, quantize_q=0.0, device=None, dtype=np.float32):

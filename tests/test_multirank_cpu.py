@@ -35,6 +35,11 @@ def _worker(rank, world, port, total, out_path):
         local = dict(R=torch.from_numpy(r["R"].astype(np.float32)), t=torch.from_numpy(r["t"].astype(np.float32)),
                      iters=torch.from_numpy(r["iters"]))
         full = pnp.gather_results(local)
+        rooted = pnp.gather_results(local, dst=1)        # the same slices on one rank only
+        if rank == 1:
+            assert all(torch.equal(rooted[k], full[k]) for k in full)
+        else:
+            assert rooted is None
         # whole-job time is the slowest rank's, as bench.py reports it
         tmax = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
