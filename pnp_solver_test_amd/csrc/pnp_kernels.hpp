@@ -368,17 +368,18 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_QEIF_WAVES) void qeif_moment_k
         return ss;
     };
     QeifState st;
-    qeif_init(st, p, 1.0);
+    qeif_init(st, p, p.q_inv);
     const QeifRule rule(p);
     const QeifNoise noise(p);
-    const double n = static_cast<double>(N);
+    moments_scale(M, p.q_inv);
+    const double n = p.q_inv * static_cast<double>(N);
     while (st.k < p.max_it) {
         if (qeif_moment_iterate(st, M, n, p, rule, noise, exact_ss)) break;
     }
     double R[9], t[3];
     qeif_finish(st, R, t);
     store_pose(problem, R, t, R_out, t_out);
-    if (res_out) res_out[problem] = static_cast<T>(qeif_residual(st, 1.0));
+    if (res_out) res_out[problem] = static_cast<T>(qeif_residual(st, p.c_inv));
     if (iters_out) iters_out[problem] = st.k;
     if (rpy_out) store_rpy(problem, R, rpy_out);
 }

@@ -394,6 +394,29 @@ __device__ __forceinline__ void moments_add(Moments &M, double X, double Y, doub
     moments_add_axes(M, pp, pt, bx, by);
 }
 
+// All sums times w (= q_inv), once after the accumulation: H^T H, H^T r and |r|^2 then come out
+// of the moment expressions already weighted, and accumulate straight into Omega.
+__device__ __forceinline__ void moments_scale(Moments &M, double w)
+{
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        M.S0[i] *= w;
+        M.ax.S1[i] *= w;
+        M.ay.S1[i] *= w;
+        M.S2[i] *= w;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        M.m0[i] *= w;
+        M.ax.m1[i] *= w;
+        M.ay.m1[i] *= w;
+        M.m2[i] *= w;
+    }
+    M.ax.b1 *= w;
+    M.ay.b1 *= w;
+    M.b2 *= w;
+}
+
 // y = S v for a packed symmetric 3x3
 __device__ __forceinline__ void sym3_mul(const double (&S)[6], const double (&v)[3], double (&y)[3])
 {
@@ -407,14 +430,15 @@ __device__ __forceinline__ double dot3(const double (&a)[3], const double (&b)[3
     return __builtin_fma(a[0], b[0], __builtin_fma(a[1], b[1], a[2] * b[2]));
 }
 
-// One axis' share of H^T H (AA: packed lower 4x4, accumulated), sum a, sum a r, sum r, sum r^2,
-// without the terms in S2, m2 and b2 (added once for both axes by the caller).
+// One axis' share of H^T H (added to AA, the packed lower 6x6 information matrix: the (q,q)
+// block, and sum a into row `row` = 4 or 5), sum a r, sum r, sum r^2, without the terms in S2, m2
+// and b2 (added once for both axes by the caller).  The sums, n included, carry the weight q_inv.
 // Qa and Q3 are 3x4 (derivatives of phia, phi3 with respect to q).
 __device__ __forceinline__ void moment_axis_terms(const double (&S0)[6], const double (&m0)[3], double n,
                                                   const AxisMoments &A, const double (&Qa)[3][4],
                                                   const double (&Q3)[3][4], const double (&phia)[3],
-                                                  const double (&phi3)[3], double d, double (&AA)[10],
-                                                  double (&sa)[4], double (&ga)[4], double &gd, double &rr)
+                                                  const double (&phi3)[3], double d, double (&AA)[21],
+                                                  int row, double (&ga)[4], double &gd, double &rr)
 {
     double s0a[3], s1a[3], s13[3], w1[3], w2[3];
     sym3_mul(S0, phia, s0a);
@@ -440,7 +464,7 @@ __device__ __forceinline__ void moment_axis_terms(const double (&S0)[6], const d
             const double ri[3] = {Q3[0][i], Q3[1][i], Q3[2][i]};
             AA[tri(i, j)] += dot3(qi, U) - dot3(ri, v0);
         }
-        sa[j] = dot3(qa, m0) - dot3(q3, A.m1);
+        AA[tri(row, j)] += dot3(qa, m0) - dot3(q3, A.m1);
         ga[j] = dot3(qa, w1) - dot3(q3, w2);
     }
     const double m1p3 = dot3(A.m1, phi3), m0pa = dot3(m0, phia);
@@ -450,8 +474,9 @@ __device__ __forceinline__ void moment_axis_terms(const double (&S0)[6], const d
     rr = __builtin_fma(-2.0, t_bf, t_ff);
 }
 
-// One iteration from the moments; same state and recurrence as qeif_iterate.  exact_ss()
-// returns the point-by-point sum of squared residuals at the current x.
+// One iteration from the moments (M and n weighted by q_inv, see moments_scale); same state and
+// recurrence as qeif_iterate, residuals in its units (squared residual times q_inv).  exact_ss()
+// returns the unweighted point-by-point sum of squared residuals at the current x.
 template <typename ExactResidual>
 __device__ __forceinline__ bool qeif_moment_iterate(QeifState &st, const Moments &M, double n,
                                                     const QeifParams &p, const QeifRule &rule,
@@ -473,14 +498,12 @@ __device__ __forceinline__ bool qeif_moment_iterate(QeifState &st, const Moments
     const double phi1[3] = {phi[0], phi[1], phi[2]};
     const double phi2[3] = {phi[3], phi[4], phi[5]};
     const double phi3[3] = {phi[6], phi[7], phi[8]};
-    double AA[10], sax[4], say[4], gax[4], gay[4], gdx, gdy, rrx, rry;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) AA[i] = 0.0;
-    moment_axis_terms(M.S0, M.m0, n, M.ax, Q1, Q3, phi1, phi3, x[4], AA, sax, gax, gdx, rrx);
-    moment_axis_terms(M.S0, M.m0, n, M.ay, Q2, Q3, phi2, phi3, x[5], AA, say, gay, gdy, rry);
+    double gax[4], gay[4], gdx, gdy, rrx, rry;
+    moment_axis_terms(M.S0, M.m0, n, M.ax, Q1, Q3, phi1, phi3, x[4], T, 4, gax, gdx, rrx);
+    moment_axis_terms(M.S0, M.m0, n, M.ay, Q2, Q3, phi2, phi3, x[5], T, 5, gay, gdy, rry);
     // the second-order terms, once for both axes: Q3^T S2 Q3 into H^T H, -Q3^T (m2 + S2 phi3) into
     // the gradient, b2 + 2 m2.phi3 + phi3^T S2 phi3 into |r|^2
-    double s23[3], gq[4];
+    double s23[3], g[6];
     sym3_mul(M.S2, phi3, s23);
     const double wc[3] = {M.m2[0] + s23[0], M.m2[1] + s23[1], M.m2[2] + s23[2]};
 #pragma unroll
@@ -491,25 +514,16 @@ __device__ __forceinline__ bool qeif_moment_iterate(QeifState &st, const Moments
 #pragma unroll
         for (int i = j; i < 4; ++i) {
             const double ri[3] = {Q3[0][i], Q3[1][i], Q3[2][i]};
-            AA[tri(i, j)] += dot3(ri, y);
+            T[tri(i, j)] += dot3(ri, y);
         }
-        gq[j] = (gax[j] + gay[j]) - dot3(q3, wc);
+        g[j] = (gax[j] + gay[j]) - dot3(q3, wc);
     }
+    g[4] = gdx;
+    g[5] = gdy;
+    T[tri(4, 4)] += n;
+    T[tri(5, 5)] += n;
     double ss = (rrx + rry) + (__builtin_fma(2.0, dot3(M.m2, phi3), M.b2) + dot3(phi3, s23));
-    if (!(ss >= kMomentResidualFloor * M.b2)) ss = exact_ss(x);
-
-    // Omega = Obar + q_inv H^T H
-    const double w = p.q_inv;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j <= i; ++j) T[tri(i, j)] = __builtin_fma(w, AA[tri(i, j)], T[tri(i, j)]);
-        T[tri(4, i)] = __builtin_fma(w, sax[i], T[tri(4, i)]);
-        T[tri(5, i)] = __builtin_fma(w, say[i], T[tri(5, i)]);
-    }
-    T[tri(4, 4)] = __builtin_fma(w, n, T[tri(4, 4)]);
-    T[tri(5, 5)] = __builtin_fma(w, n, T[tri(5, 5)]);
-    double g[6] = {w * gq[0], w * gq[1], w * gq[2], w * gq[3], w * gdx, w * gdy};
+    if (!(ss >= kMomentResidualFloor * M.b2)) ss = p.q_inv * exact_ss(x);
     return qeif_correct(st, g, ss, rule);
 }
 
