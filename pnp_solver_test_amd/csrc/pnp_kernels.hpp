@@ -334,13 +334,17 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_QEIF_WAVES) void qeif_moment_k
         __syncthreads();
         if (c0 + C < N) prefetch(c0 + C);
         if (tid < nprob) {
-            Staged cur, nxt;
-            fetch(c0, 0, nxt);
+            // two points per trip, their registers alternating: the LDS reads of one point are
+            // in flight while the other is accumulated (a single rotating pair of variables gets
+            // folded by the compiler into read-then-use within one trip)
+            Staged pa, pb;
+            fetch(c0, 0, pa);
 #pragma unroll 1
-            for (int i = 0; i < cn; ++i) {
-                cur = nxt;
-                fetch(c0, min(i + 1, cn - 1), nxt);
-                accumulate(cur);
+            for (int i = 0; i < cn; i += 2) {
+                fetch(c0, min(i + 1, cn - 1), pb);
+                accumulate(pa);
+                fetch(c0, min(i + 2, cn - 1), pa);
+                if (i + 1 < cn) accumulate(pb);
             }
         }
     }
