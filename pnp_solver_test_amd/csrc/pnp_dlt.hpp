@@ -80,10 +80,9 @@ __device__ __forceinline__ void dlt_solve(const PointFetch &pts, int N, int lane
         for (int i = 0; i < 10; ++i) M[i] = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) rx[i] = ry[i] = 0.0;
-        auto accumulate = [&](int i) {
+        auto add_row = [&](int i, double w) {
             double X, Y, Z, bx, by;
             pts(i, X, Y, Z, bx, by);
-            const double w = rcp(dlt_depth_factor(X, Y, Z, phi3));
             const double d[4] = {X * w, Y * w, Z * w, w};
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
@@ -93,11 +92,32 @@ __device__ __forceinline__ void dlt_solve(const PointFetch &pts, int N, int lane
                 ry[a] = __builtin_fma(d[a], by, ry[a]);
             }
         };
+        auto depth = [&](int i) {
+            double X, Y, Z, bx, by;
+            pts(i, X, Y, Z, bx, by);
+            return dlt_depth_factor(X, Y, Z, phi3);
+        };
+        double wts[NCT > 0 ? NCT : 1];
         if constexpr (NCT > 0) {
+            // 1/Delta_i of all NCT points from one reciprocal (of their product) and 3 (NCT - 1)
+            // multiplications; the factors are clamped away from zero and of order one
+            double D[NCT], pre[NCT];
 #pragma unroll
-            for (int i = 0; i < NCT; ++i) accumulate(i);
+            for (int i = 0; i < NCT; ++i) {
+                D[i] = depth(i);
+                pre[i] = (i == 0) ? D[0] : pre[i - 1] * D[i];
+            }
+            double inv = rcp(pre[NCT - 1]);
+#pragma unroll
+            for (int i = NCT - 1; i > 0; --i) {
+                wts[i] = inv * pre[i - 1];
+                inv *= D[i];
+            }
+            wts[0] = inv;
+#pragma unroll
+            for (int i = 0; i < NCT; ++i) add_row(i, wts[i]);
         } else {
-            for (int i = lane_in_group; i < N; i += LPI) accumulate(i);
+            for (int i = lane_in_group; i < N; i += LPI) add_row(i, rcp(depth(i)));
         }
         if (LPI > 1) {
 #pragma unroll
@@ -119,7 +139,7 @@ __device__ __forceinline__ void dlt_solve(const PointFetch &pts, int N, int lane
             auto residual = [&](int i) {
                 double X, Y, Z, bx, by;
                 pts(i, X, Y, Z, bx, by);
-                const double w = rcp(dlt_depth_factor(X, Y, Z, phi3));
+                const double w = (NCT > 0) ? wts[NCT > 0 ? i : 0] : rcp(dlt_depth_factor(X, Y, Z, phi3));
                 const double ex = bx - w * __builtin_fma(X, fx[0], __builtin_fma(Y, fx[1], __builtin_fma(Z, fx[2], fx[3])));
                 const double ey = by - w * __builtin_fma(X, fy[0], __builtin_fma(Y, fy[1], __builtin_fma(Z, fy[2], fy[3])));
                 ss = __builtin_fma(ex, ex, __builtin_fma(ey, ey, ss));
