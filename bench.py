@@ -8,10 +8,13 @@ in HBM.  The default workload is the configuration the headline metric is quoted
 "Batched PnP + LM refine, N=6, batch=1M fp32" = the quaternion information-filter solver
 (QEIF, the reference's live solve_pnp path) with its reference defaults on 1,048,576
 six-point problems per GPU, every problem carrying its own 3-D points (uv 8N + xyz 12N bytes
-in, R 36 + t 12 bytes out = 168 algorithmic bytes per solve).  With N > 1 ranks (launched by
-torch.distributed.run) every rank solves its own 1M-problem slice - weak scaling, no
-collective on the data path - and the reported value is all ranks' solves over the slowest
-rank's time.
+in, R 36 + t 12 bytes out = 168 algorithmic bytes per solve).  With N > 1 ranks every rank
+solves its own 1M-problem slice - weak scaling, no collective on the data path - and the
+reported value is all ranks' solves over the slowest rank's time.  The ranks are either started
+from outside (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: RANK is
+set and this process is one of them) or, for a plain `python bench.py --gpus N`, by this process
+itself: before it imports torch or touches a device it starts that same torch.distributed.run
+command as a child, relays the child's output and exits with its status.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      algorithmic HBM bytes of the dominant kernel / its mean launch time (HIP events
@@ -40,7 +43,24 @@ BATCH = 1 << 20
 N_POINTS = 6
 
 
-SPINUP_STEPS = 100   # untimed launches before the W warm-up steps (see main)
+SAMPLE_EVERY = 8     # every 8th timed launch is bracketed by an event pair of its own
+SPINUP_MS = 60.0     # every measurement is preceded by at least this much untimed GPU work
+
+
+def spin_up(torch, fn, min_ms=SPINUP_MS):
+    """Clock spin-up, part of set-up and reported as such: an idle MI355X needs some tens of
+    milliseconds of work before it holds its compute clock.  Launches `fn` in groups of 16 until
+    `min_ms` of wall-clock have passed with the device busy; returns the number of launches.  The
+    headline and every variant beside it use this one rule."""
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        for _ in range(16):
+            fn()
+        n += 16
+        torch.cuda.synchronize()
+        if (time.perf_counter() - t0) * 1e3 >= min_ms:
+            return n
 
 
 def qeif_flops(n_points, iters_mean):
@@ -68,9 +88,10 @@ def dlt_flops(n_points, num_it=3):
     return 2.0 * (num_it * (30.0 * n_points + 110.0) + 20.0 * n_points)
 
 
-def time_launches(torch, fn, steps, warmup):
+def time_launches(torch, fn, steps, warmup=8):
     """Mean per-launch device time (ms): one HIP event pair on the current (= launch) stream
-    around `steps` back-to-back launches."""
+    around `steps` back-to-back launches, after the common spin-up and `warmup` more launches."""
+    spin_up(torch, fn)
     for _ in range(warmup):
         fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -149,6 +170,71 @@ def cpu_baseline_c(uv, xyz, K):
                 sample="first %d problems, scalar C float64 (oracle/pnp_oracle.c), %.1f s" % (n, dt))
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n_ranks, argv):
+    """Starts the N ranks of `python bench.py --gpus N` as children of this process:
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <argv>`.  Called
+    before this process has imported torch or made any HIP call, and it never replaces itself by
+    another program: it waits for the child, relays its output (rank 0's JSON line is the last
+    line of stdout) and returns the child's exit status."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL needs dmabuf IPC on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n_ranks,
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    json_lines = [ln for ln in lines if ln.lstrip().startswith("{") and '"metric"' in ln]
+    for ln in lines:
+        if ln not in json_lines:
+            print(ln, file=sys.stderr)
+    if json_lines:
+        print(json_lines[-1], flush=True)
+    elif proc.returncode == 0:
+        print("bench.py: the ranks exited without printing a result line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
+def launcher_check(args):
+    """The rank plumbing of an N-rank run without the solver, on the gloo backend (no GPU
+    needed): rendezvous from the environment torch.distributed.run sets, this rank's slice of the
+    job, the barriers around the timed region and the max-over-ranks time.  Rank 0 prints a line
+    of the usual shape with "launcher_check": true and no value."""
+    import torch
+    import torch.distributed as dist
+
+    import pnp_solver_test_amd as pnp
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist.init_process_group("gloo")
+    lo, hi = pnp.shard_bounds(world * args.batch, rank, world)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0 + rank], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    sizes = torch.zeros(world, dtype=torch.int64)
+    sizes[rank] = hi - lo
+    dist.all_reduce(sizes)
+    if rank == 0:
+        print(json.dumps({"metric": "PnP solves/sec (N=6, LM 5 iters)", "value": None, "unit": "solves/s",
+                          "n_gpus": world, "rccl_ranks": 0, "backend": "gloo", "launcher_check": True,
+                          "steps": args.steps, "warmup": args.warmup, "slice_sizes": sizes.tolist(),
+                          "slowest_rank_offset_s": int(tmax.item())}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,7 +243,20 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="problems per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--launcher-check", action="store_true",
+                    help="run only the N-rank plumbing on the gloo backend (no GPU, no solver)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # nothing in this process has touched torch or HIP yet
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.launcher_check:
+        if "RANK" not in os.environ:
+            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                              MASTER_PORT=str(free_port()))
+        return launcher_check(args)
 
     import torch
     import torch.distributed as dist
@@ -169,12 +268,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the solver has no CPU path")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d wants device %d but only %d are visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    distributed = "RANK" in os.environ          # launched by torch.distributed.run, any world size
+    distributed = "RANK" in os.environ          # one of the ranks of torch.distributed.run, any world size
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -197,25 +298,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Clock spin-up, part of set-up and reported as such: an idle MI355X needs some tens of
-    # milliseconds of work before it holds its compute clock, whatever W the caller asks for.
-    for _ in range(SPINUP_STEPS):
-        out = step()
+    spinup_steps = spin_up(torch, step)
     for _ in range(args.warmup):
         out = step()
     barrier()
     # One HIP event pair on the launch stream around the K launches: its span / K is the mean
     # launch duration, gaps between launches included.  (A pair around every launch puts two
-    # markers between consecutive kernels and costs the loop 3 % of wall-clock.)
+    # markers between consecutive kernels and costs the loop 3 % of wall-clock, so only every
+    # SAMPLE_EVERY-th launch carries a pair of its own, for the minimum and the median.)
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    samples = []
     t0 = time.perf_counter()
     ev_a.record()
-    for _ in range(args.steps):
-        out = step()
+    for i in range(args.steps):
+        if i % SAMPLE_EVERY == SAMPLE_EVERY - 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = step()
+            e1.record()
+            samples.append((e0, e1))
+        else:
+            out = step()
     ev_b.record()
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev_a.elapsed_time(ev_b) / args.steps
+    sampled = sorted(a.elapsed_time(b) for a, b in samples)
     if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -260,11 +368,17 @@ def main():
         bytes_per_solve = 20 * N_POINTS + 48
         achieved = B * bytes_per_solve / (kernel_ms * 1e-3) / 1e9
         flops = qeif_flops(N_POINTS, iters_mean)
-        traffic = None
+        traffic_table = {}
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get("qeif_n6_b1m_bytes_per_launch")
+                traffic_table = json.load(f)
+
+        def traffic_of(key):
+            """HBM bytes per launch from the PMC passes (profiles/hbm_traffic.json), or None."""
+            return traffic_table.get(key)
+
+        traffic = traffic_of("qeif_n6_b1m_bytes_per_launch")
         line = {
             "metric": "PnP solves/sec (N=6, LM 5 iters)",
             "value": round(value, 1),
@@ -272,12 +386,15 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "spinup_steps": SPINUP_STEPS,
+            "rccl_ranks": world if distributed else 0,
+            "spinup_steps": spinup_steps,
+            "spinup_rule": ">= %.0f ms of untimed launches before every measurement" % SPINUP_MS,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
+            "io_dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[2]: batched PnP + LM refine = QEIF solver, reference defaults "
@@ -299,6 +416,9 @@ def main():
                 "traffic": traffic,
                 "kernel": "pnp::qeif_kernel<1,6>",
                 "kernel_ms": round(kernel_ms, 4),
+                "kernel_ms_min": round(sampled[0], 4) if sampled else None,
+                "kernel_ms_median": round(sampled[len(sampled) // 2], 4) if sampled else None,
+                "kernel_ms_samples": len(sampled),
                 "bytes_per_solve": bytes_per_solve,
                 "note": "168 B and ~%.0f float64 flops per solve (%.0f flop/B): the kernel is bound by the "
                         "vector ALU, see roofline_valu" % (flops, flops / bytes_per_solve),
@@ -317,26 +437,29 @@ def main():
         if world == 1 and not args.no_other_configs:
             other = {}
             n_small = max(5, min(50, args.steps // 2))
-            # every variant gets its own spin-up: the host work between two variants leaves the GPU
-            # idle long enough for its clock to drop, and the first ~30 ms of launches run slow
-            n_spin = 200
+            # every variant gets the same spin-up as the headline (time_launches): the host work
+            # between two variants leaves the GPU idle long enough for its clock to drop
             P6 = torch.from_numpy(synth.PATTERN6.astype(np.float32)).to(dev)
-            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, P6, K, want_rpy=False), n_small, n_spin)
+            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, P6, K, want_rpy=False), n_small)
             other["qeif_n6_shared_pattern"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4),
                                                    bytes_per_solve=8 * N_POINTS + 48)
             p5 = pnp.make_params(max_it=5, rel_tol=0.0)
-            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, xyz, K, params=p5, want_rpy=False), n_small, n_spin)
+            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, xyz, K, params=p5, want_rpy=False), n_small)
             other["qeif_n6_fixed_5_iterations"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4))
-            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, xyz, K, want_rpy=True), n_small, n_spin)
+            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, xyz, K, want_rpy=True), n_small)
             other["qeif_n6_with_euler_output"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4))
-            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, xyz, K, method="dlt", want_rpy=False), n_small, n_spin)
+            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, xyz, K, method="dlt", want_rpy=False), n_small)
             gbs = B * bytes_per_solve / (ms * 1e-3) / 1e9
-            other["configs[1]_dlt_n6_b1m"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4),
-                                                  achieved_GBps=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4),
-                                                  valu_fp64_TFLOPs=round(B * dlt_flops(6) / (ms * 1e-3) / 1e12, 2))
+            other["configs[1]_dlt_n6_b1m"] = dict(
+                solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4),
+                achieved_GBps=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4),
+                valu_fp64_TFLOPs=round(B * dlt_flops(6) / (ms * 1e-3) / 1e12, 2),
+                roofline=dict(bound="hbm", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                              frac=round(gbs / HBM_PEAK_GBS, 5), traffic=traffic_of("dlt_n6_b1m_per_problem_xyz_bytes_per_launch"),
+                              kernel="pnp::dlt_kernel<1,6>", kernel_ms=round(ms, 4), bytes_per_solve=bytes_per_solve))
             B_lm = 1 << 18
             ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv[:B_lm], xyz[:B_lm], K, method="lm12", want_rpy=False),
-                               10, 25)
+                               10)
             other["lm12_n6_b256k (secondary solver)"] = dict(solves_per_s=round(B_lm / ms * 1e3, 1), kernel_ms=round(ms, 4))
             B68 = 1 << 18
             P68 = synth.face68()
@@ -348,7 +471,7 @@ def main():
             it68 = float(o68["iters"].float().mean().item())
             own68 = P68d[None].expand(B68, 68, 3).contiguous()
             for tag, xyz68, nbytes in (("shared_pattern", P68d, 8 * 68 + 48), ("per_problem_pattern", own68, 20 * 68 + 48)):
-                ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv68, xyz68, K, want_rpy=False), n_small, n_spin)
+                ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv68, xyz68, K, want_rpy=False), n_small)
                 gbs = B68 * nbytes / (ms * 1e-3) / 1e9
                 other["configs[3]_qeif_n68_b256k_" + tag] = dict(
                     solves_per_s=round(B68 / ms * 1e3, 1), kernel_ms=round(ms, 4), mean_iterations=round(it68, 3),
@@ -356,19 +479,21 @@ def main():
                     form="moments" if lib.pnp_get_qeif_form(B68, 68) == pnp._lib.QEIF_FORM_MOMENTS else "points",
                     valu_fp64_TFLOPs=round(B68 * qeif_moment_flops(68, it68) / (ms * 1e-3) / 1e12, 2))
             lib.pnp_set_qeif_form(pnp._lib.QEIF_FORM_POINTS)        # the point-by-point form, for comparison
-            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv68, P68d, K, want_rpy=False), 10, 25)
-            lib.pnp_set_qeif_form(pnp._lib.QEIF_FORM_AUTO)
+            try:
+                ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv68, P68d, K, want_rpy=False), 10)
+            finally:
+                lib.pnp_set_qeif_form(pnp._lib.QEIF_FORM_AUTO)
             other["configs[3]_qeif_n68_b256k_shared_pattern_point_form"] = dict(
                 solves_per_s=round(B68 / ms * 1e3, 1), kernel_ms=round(ms, 4),
                 lanes_per_problem=lib.pnp_get_lanes_per_problem(B68, 68, 0),
                 valu_fp64_TFLOPs=round(B68 * qeif_flops(68, it68) / (ms * 1e-3) / 1e12, 2))
             del own68
             uv64, xyz64 = uv.double(), xyz.double()          # the reference's own dtype end to end
-            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv64, xyz64, K, want_rpy=False), n_small, n_spin)
+            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv64, xyz64, K, want_rpy=False), n_small)
             other["qeif_n6_b1m_float64_io"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4),
                                                    bytes_per_solve=2 * bytes_per_solve)
             ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv64, xyz64, K, method="dlt", want_rpy=False),
-                               n_small, n_spin)
+                               n_small)
             gbs = B * (2 * bytes_per_solve) / (ms * 1e-3) / 1e9
             other["dlt_n6_b1m_float64_io"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4),
                                                   achieved_GBps=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4))

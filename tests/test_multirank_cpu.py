@@ -66,3 +66,44 @@ def test_two_rank_slices_and_gather(tmp_path, total):
     assert np.array_equal(got["R"], ref["R"].astype(np.float32))
     assert np.array_equal(got["t"], ref["t"].astype(np.float32))
     assert np.array_equal(got["iters"], ref["iters"])
+
+
+@pytest.mark.timeout(180)
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no RANK in the environment starts two ranks itself (a child
+    `torch.distributed.run`), relays rank 0's JSON line as the last line of stdout and exits with
+    the child's status.  --launcher-check runs the rank plumbing on gloo without the solver."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-check",
+                           "--steps", "3", "--batch", "1001"], env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=170)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = json.loads(proc.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["launcher_check"] is True
+    assert line["slice_sizes"] == [1001, 1001]           # weak scaling: --batch problems per rank
+    assert line["slowest_rank_offset_s"] == 1            # the max over ranks, not rank 0's own time
+
+
+@pytest.mark.timeout(180)
+def test_bench_launcher_passes_a_failure_on():
+    """Without a GPU the real two-rank bench cannot run: the launcher must hand the ranks' failure
+    to its caller as a non-zero status instead of printing a result."""
+    import subprocess
+    import sys
+
+    import torch
+    from conftest import ROOT
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the ranks would run")
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=170)
+    assert proc.returncode != 0
+    assert '"metric"' not in proc.stdout
