@@ -106,6 +106,29 @@ int pnp_lm12_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_st
                        float *R_out, float *t_out, float *res_out, float *rpy_out,
                        int32_t ptr_kind, void *hip_stream);
 
+/* pnp_qeif_batch_f32 for host pointers (PNP_PTR_HOST), allocating nothing.  It has no
+ * counterpart in the reference; it is for callers that cannot allocate device memory: tight
+ * serving loops, harnesses that forbid hipMalloc, code that must not change the process's memory
+ * footprint.  pnp_qeif_batch_f32 stages host arrays through a device buffer it obtains from
+ * hipMalloc (and grows with hipFree + hipMalloc); this entry point stages them through a static
+ * device array of PNP_NOALLOC_SCRATCH_BYTES bytes that every GPU the library runs on holds for
+ * the life of the process.  It calls no hipMalloc, hipFree or hipHostMalloc.
+ *   - Arguments and results are exactly those of pnp_qeif_batch_f32 with ptr_kind = PNP_PTR_HOST
+ *     (same kernels, bit-identical outputs); xyz_problem_stride is 0 or 3*N.
+ *   - Limit: the staged arrays - B*(8N [+ 12N with per-problem xyz] + 68) bytes plus the shared
+ *     pattern, each of eight pieces padded to 256 bytes - must fit the static array; a larger
+ *     call fails with PNP_E_ARG and names the largest B that fits (about 89 000 six-point
+ *     problems with per-problem xyz).  Split larger batches.
+ *   - Every call on one GPU uses that GPU's one array.  Calls of one process on one GPU are
+ *     serialised by a lock held until the results are back; nothing in the array has to start
+ *     at zero and nothing is kept between calls.  The device address of the array is resolved
+ *     by pnp_init(device) or, failing that, by the first call on a device. */
+#define PNP_NOALLOC_SCRATCH_BYTES (16u << 20)
+int pnp_qeif_batch_noalloc_f32(const float *uv, const float *xyz, int64_t xyz_problem_stride,
+                               const double K[9], int64_t B, int32_t N, const pnp_qeif_params *p,
+                               float *R_out, float *t_out, float *res_out, int32_t *iters_out,
+                               float *rpy_out, void *hip_stream);
+
 /* Replaces get_Euler_from_rotation_matrix(R, is_degree=True) (PNP_SOLVER_LIB.py:4474-4517)
  * for B matrices: R (B,9) -> rpy (B,3) = roll, yaw, pitch in degrees. */
 int pnp_euler_deg_f32(const float *R, int64_t B, float *rpy, int32_t ptr_kind, void *hip_stream);

@@ -26,6 +26,7 @@ LIB_PATH = os.environ.get("PNP_HIP_LIB") or os.path.join(_HERE, "libpnp_hip.so")
 PTR_HOST = 0
 PTR_DEVICE = 1
 QEIF_FORM_AUTO, QEIF_FORM_POINTS, QEIF_FORM_MOMENTS = 0, 1, 2
+NOALLOC_SCRATCH_BYTES = 16 << 20      # PNP_NOALLOC_SCRATCH_BYTES
 
 #: every symbol include/pnp_hip.h declares
 EXPORTS = (
@@ -34,7 +35,7 @@ EXPORTS = (
     "pnp_qeif_batch_f64", "pnp_dlt_batch_f64", "pnp_lm12_batch_f64", "pnp_euler_deg_f64",
     "pnp_qeif_multi_batch_f64", "pnp_project_batch_f64", "pnp_compare_batch_f32", "pnp_compare_batch_f64",
     "pnp_set_lanes_per_problem", "pnp_get_lanes_per_problem", "pnp_set_qeif_form", "pnp_get_qeif_form",
-    "pnp_max_points",
+    "pnp_max_points", "pnp_qeif_batch_noalloc_f32",
     "pnp_last_error", "pnp_version",
 )
 
@@ -87,6 +88,8 @@ def load():
             fn = getattr(lib, name + sfx)
             fn.argtypes = args
             fn.restype = ctypes.c_int
+    lib.pnp_qeif_batch_noalloc_f32.argtypes = [vp, vp, i64, dp, i64, i32, pp, vp, vp, vp, vp, vp, vp]
+    lib.pnp_qeif_batch_noalloc_f32.restype = ctypes.c_int
     lib.pnp_project_batch_f64.argtypes = [vp, vp, vp, i64, dp, i64, i32, ctypes.c_double, vp, i32, i32, vp]
     lib.pnp_project_batch_f64.restype = ctypes.c_int
     lib.pnp_set_lanes_per_problem.argtypes = [i32]

@@ -17,6 +17,12 @@
 
 #include "pnp_kernels.hpp"
 
+// Staging memory of pnp_qeif_batch_noalloc_f32, the entry point that allocates nothing: every
+// device the library's code object is loaded on holds its own copy of this array until the
+// process ends.  In host code the name is only a handle for hipGetSymbolAddress; the device
+// address it yields (one per device, see scratch_address) is what copies and kernels are given.
+static __device__ __align__(256) unsigned char scratch[PNP_NOALLOC_SCRATCH_BYTES];
+
 namespace {
 
 using pnp::kBlock;
@@ -94,6 +100,38 @@ struct Carver {
         return p;
     }
 };
+
+// Synchronises a stream when it goes out of scope unless dismissed: an error exit after the first
+// enqueue must not hand the staging buffers to the next caller while copies are in flight.
+struct SyncOnExit {
+    hipStream_t s;
+    bool armed = true;
+    explicit SyncOnExit(hipStream_t st) : s(st) {}
+    ~SyncOnExit() { if (armed) (void)hipStreamSynchronize(s); }
+    SyncOnExit(const SyncOnExit &) = delete;
+    SyncOnExit &operator=(const SyncOnExit &) = delete;
+};
+
+// Device address of `scratch` on each device, resolved once per device with that device current.
+struct StaticScratch {
+    std::mutex mu;
+    void *ptr = nullptr;
+};
+StaticScratch g_scratch[kMaxDevices];
+
+// Caller holds g_scratch[dev].mu and `dev` is the current device.
+int scratch_address(int dev, void **out)
+{
+    StaticScratch &sc = g_scratch[dev];
+    if (!sc.ptr) {
+        void *p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(PNP_E_HIP, "hipGetSymbolAddress gave no address for the static staging array");
+        sc.ptr = p;
+    }
+    *out = sc.ptr;
+    return PNP_OK;
+}
 
 // ---- small host helpers --------------------------------------------------------------------
 
@@ -357,6 +395,7 @@ int with_host_staging(hipStream_t s, int64_t B, int32_t N, size_t xyz_elems, con
     d.iters = h.iters ? c.take<int32_t>(nB) : nullptr;
     d.pid = h.pid ? c.take<int32_t>(nB) : nullptr;
     const size_t all_bytes = c.off;
+    SyncOnExit guard(s);   // every exit below, error or not, leaves no copy in flight
 
     if (all_bytes <= kSmallCall) {
         // small call: gather the inputs in the pinned mirror, one copy each way
@@ -396,10 +435,10 @@ int with_host_staging(hipStream_t s, int64_t B, int32_t N, size_t xyz_elems, con
 
 // ---- entry-point bodies, shared by the float32 and float64 flavours -----------------------------
 
-template <typename T>
-int qeif_impl(const T *uv, const T *xyz, int64_t xyz_stride, int32_t n_patterns, const double K[9], int64_t B,
-              int32_t N, const pnp_qeif_params *p, T *R_out, T *t_out, T *res_out, int32_t *iters_out,
-              T *rpy_out, int32_t *pid_out, int32_t ptr_kind, void *hip_stream)
+// Argument checks and host-side constants shared by every QEIF entry point.
+int qeif_prepare(const void *uv, const void *xyz, int64_t xyz_stride, int32_t n_patterns, const double K[9], int64_t B,
+                 int32_t N, const pnp_qeif_params *p, const void *R_out, const void *t_out, int32_t ptr_kind,
+                 pnp::KinvRows &ki, pnp::QeifParams &q)
 {
     g_err[0] = 0;
     int rc = check_common(uv, xyz, xyz_stride, K, B, N, R_out, t_out, ptr_kind);
@@ -410,23 +449,91 @@ int qeif_impl(const T *uv, const T *xyz, int64_t xyz_stride, int32_t n_patterns,
     if (p && !(p->q_inv > 0.0 && p->r_quat > 0.0 && p->r_delta > 0.0 && p->omega0 > 0.0))
         return fail(PNP_E_ARG, "q_inv = %g, r_quat = %g, r_delta = %g and omega0 = %g must all be > 0", p->q_inv,
                     p->r_quat, p->r_delta, p->omega0);
-    pnp::KinvRows ki;
     rc = kinv_rows(K, ki);
     if (rc) return rc;
-    const pnp::QeifParams q = to_device_params(p);
+    q = to_device_params(p);
+    if (ptr_kind == PNP_PTR_HOST && xyz_stride != 0 && xyz_stride != 3 * static_cast<int64_t>(N))
+        return fail(PNP_E_ARG, "host-pointer calls take xyz_problem_stride 0 or 3*N only");
+    return PNP_OK;
+}
+
+template <typename T>
+int qeif_impl(const T *uv, const T *xyz, int64_t xyz_stride, int32_t n_patterns, const double K[9], int64_t B,
+              int32_t N, const pnp_qeif_params *p, T *R_out, T *t_out, T *res_out, int32_t *iters_out,
+              T *rpy_out, int32_t *pid_out, int32_t ptr_kind, void *hip_stream)
+{
+    pnp::KinvRows ki;
+    pnp::QeifParams q;
+    int rc = qeif_prepare(uv, xyz, xyz_stride, n_patterns, K, B, N, p, R_out, t_out, ptr_kind, ki, q);
+    if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     if (B == 0) return PNP_OK;
     if (ptr_kind == PNP_PTR_DEVICE)
         return launch_qeif<T>(s, uv, xyz, xyz_stride, n_patterns, ki, B, N, q, R_out, t_out, res_out, iters_out,
                               rpy_out, pid_out);
-    if (xyz_stride != 0 && xyz_stride != 3 * static_cast<int64_t>(N))
-        return fail(PNP_E_ARG, "host-pointer calls take xyz_problem_stride 0 or 3*N only");
     const size_t xyz_elems = xyz_stride ? static_cast<size_t>(B) * 3 * N : static_cast<size_t>(n_patterns) * 3 * N;
     SolveIO<T> h{uv, xyz, R_out, t_out, res_out, rpy_out, iters_out, pid_out};
     return with_host_staging<T>(s, B, N, xyz_elems, h, [&](const SolveIO<T> &d) {
         return launch_qeif<T>(s, d.uv, d.xyz, xyz_stride, n_patterns, ki, B, N, q, d.R, d.t, d.res, d.iters, d.rpy,
                               d.pid);
     });
+}
+
+// The host-pointer QEIF call with its staging in the static array instead of a buffer from
+// hipMalloc: no allocation, no free, no pinned mirror; copies go straight between the caller's
+// arrays and the static array.
+int qeif_noalloc(const float *uv, const float *xyz, int64_t xyz_stride, const double K[9], int64_t B, int32_t N,
+                 const pnp_qeif_params *p, float *R_out, float *t_out, float *res_out, int32_t *iters_out,
+                 float *rpy_out, void *hip_stream)
+{
+    using T = float;
+    pnp::KinvRows ki;
+    pnp::QeifParams q;
+    int rc = qeif_prepare(uv, xyz, xyz_stride, 1, K, B, N, p, R_out, t_out, PNP_PTR_HOST, ki, q);
+    if (rc) return rc;
+    if (B == 0) return PNP_OK;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const size_t nB = static_cast<size_t>(B);
+    const size_t xyz_elems = xyz_stride ? nB * 3 * N : static_cast<size_t>(3) * N;
+    // size of the carve-up below, before any pointer is formed: eight pieces, each padded to 256 bytes
+    const size_t per_problem = (2 * static_cast<size_t>(N) + (xyz_stride ? 3 * static_cast<size_t>(N) : 0) + 9 + 3 + 1 + 3) *
+                                   sizeof(T) + sizeof(int32_t);
+    if (nB > (PNP_NOALLOC_SCRATCH_BYTES - 8 * 256 - 3 * static_cast<size_t>(N) * sizeof(T)) / per_problem)
+        return fail(PNP_E_ARG,
+                    "B = %lld problems of N = %d points need more staging than the static buffer of %zu bytes "
+                    "holds (at most %zu problems in this layout): split the batch or use pnp_qeif_batch_f32",
+                    static_cast<long long>(B), N, static_cast<size_t>(PNP_NOALLOC_SCRATCH_BYTES),
+                    (PNP_NOALLOC_SCRATCH_BYTES - 8 * 256 - 3 * static_cast<size_t>(N) * sizeof(T)) / per_problem);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(PNP_E_HIP, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_scratch[dev].mu);
+    void *base = nullptr;
+    rc = scratch_address(dev, &base);
+    if (rc) return rc;
+    Carver c(base);
+    T *d_uv = c.take<T>(nB * 2 * N);
+    T *d_xyz = c.take<T>(xyz_elems);
+    T *d_R = c.take<T>(nB * 9);
+    T *d_t = c.take<T>(nB * 3);
+    T *d_res = c.take<T>(nB);
+    T *d_rpy = c.take<T>(nB * 3);
+    int32_t *d_iters = c.take<int32_t>(nB);
+    if (c.off > PNP_NOALLOC_SCRATCH_BYTES)
+        return fail(PNP_E_ARG, "staging layout of %zu bytes exceeds the static buffer", c.off);
+    SyncOnExit guard(s);
+    HIP_TRY(hipMemcpyAsync(d_uv, uv, nB * 2 * N * sizeof(T), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_xyz, xyz, xyz_elems * sizeof(T), hipMemcpyHostToDevice, s));
+    rc = launch_qeif<T>(s, d_uv, d_xyz, xyz_stride, 1, ki, B, N, q, d_R, d_t, d_res, iters_out ? d_iters : nullptr,
+                        rpy_out ? d_rpy : nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(R_out, d_R, nB * 9 * sizeof(T), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(t_out, d_t, nB * 3 * sizeof(T), hipMemcpyDeviceToHost, s));
+    if (res_out) HIP_TRY(hipMemcpyAsync(res_out, d_res, nB * sizeof(T), hipMemcpyDeviceToHost, s));
+    if (rpy_out) HIP_TRY(hipMemcpyAsync(rpy_out, d_rpy, nB * 3 * sizeof(T), hipMemcpyDeviceToHost, s));
+    if (iters_out) HIP_TRY(hipMemcpyAsync(iters_out, d_iters, nB * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return PNP_OK;
 }
 
 template <typename T>
@@ -506,6 +613,7 @@ int euler_impl(const T *R, int64_t B, T *rpy, int32_t ptr_kind, void *hip_stream
     int rc = staging_reserve(st, 1024 + nB * 12 * sizeof(T));
     if (rc) return rc;
     Carver c(st.buf);
+    SyncOnExit guard(s);
     T *d_R = c.take<T>(nB * 9);
     T *d_rpy = c.take<T>(nB * 3);
     HIP_TRY(hipMemcpyAsync(d_R, R, nB * 9 * sizeof(T), hipMemcpyHostToDevice, s));
@@ -555,6 +663,7 @@ int project_impl(const double *rpy_deg, const double *t, const double *xyz, int6
     int rc = staging_reserve(st, 2048 + (nB * 6 + xyz_n + 16) * sizeof(double) + nB * 2 * N * sizeof(T));
     if (rc) return rc;
     Carver c(st.buf);
+    SyncOnExit guard(s);
     double *d_rpy = c.take<double>(nB * 3);
     double *d_t = c.take<double>(nB * 3);
     double *d_xyz = c.take<double>(xyz_n);
@@ -610,6 +719,7 @@ int compare_impl(const T *R_est, const T *t_est, const T *uv_obs, const double *
                                      nB * 4 * sizeof(int32_t));
     if (rc) return rc;
     Carver c(st.buf);
+    SyncOnExit guard(s);
     double *d_rpy = c.take<double>(nB * 3);
     double *d_dist = c.take<double>(nB);
     double *d_xyz = c.take<double>(static_cast<size_t>(3) * M);
@@ -674,7 +784,12 @@ int pnp_init(int device)
     if (device < 0 || device >= n) return fail(PNP_E_ARG, "device %d outside [0, %d)", device, n);
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipFree(nullptr));  // forces context creation
-    return PNP_OK;
+    // this device's address of the static staging array, so that the allocation-free entry point
+    // finds it resolved
+    if (device >= kMaxDevices) return fail(PNP_E_HIP, "device index %d out of range", device);
+    std::lock_guard<std::mutex> lock(g_scratch[device].mu);
+    void *unused = nullptr;
+    return scratch_address(device, &unused);
 }
 
 // ---- float32 problem arrays ----------------------------------------------------------------------
@@ -685,6 +800,14 @@ int pnp_qeif_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_st
 {
     return qeif_impl<float>(uv, xyz, xyz_problem_stride, 1, K, B, N, p, R_out, t_out, res_out, iters_out, rpy_out,
                             nullptr, ptr_kind, hip_stream);
+}
+
+int pnp_qeif_batch_noalloc_f32(const float *uv, const float *xyz, int64_t xyz_problem_stride, const double K[9],
+                               int64_t B, int32_t N, const pnp_qeif_params *p, float *R_out, float *t_out,
+                               float *res_out, int32_t *iters_out, float *rpy_out, void *hip_stream)
+{
+    return qeif_noalloc(uv, xyz, xyz_problem_stride, K, B, N, p, R_out, t_out, res_out, iters_out, rpy_out,
+                        hip_stream);
 }
 
 int pnp_qeif_multi_batch_f32(const float *uv, const float *xyz, int32_t n_patterns, const double K[9], int64_t B,
