@@ -134,9 +134,11 @@ def project(P, K, R, t, is_quantized=False, q=1.0) -> np.ndarray:
 
 def normalized_xy(uv, K):
     """nu = K^-1 [u,v,1]^T; returns (Bx, By) = first two components, NOT divided by the
-    third (:2811-2812, :3291-3312; :3094-3111 for the DLT path)."""
+    third (:2811-2812, :3291-3312; :3094-3111 for the DLT path).  uv (N,2), or (N,3) rows
+    [u,v,w] with the homogeneous component the image dict carries (w = -1 behind the camera)."""
     K_inv = np.linalg.inv(K)
-    hom = np.concatenate([np.asarray(uv, dtype=np.float64), np.ones((len(uv), 1))], axis=1)
+    uv = np.asarray(uv, dtype=np.float64)
+    hom = uv if uv.shape[1] == 3 else np.concatenate([uv, np.ones((len(uv), 1))], axis=1)
     nu = (K_inv @ hom.T).T
     return nu[:, 0].copy(), nu[:, 1].copy()
 

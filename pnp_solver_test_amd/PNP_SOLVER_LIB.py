@@ -24,6 +24,7 @@ import copy
 
 import numpy as np
 
+from . import _geometry as _geo
 from . import _lib
 from . import batch as _batch
 
@@ -37,32 +38,35 @@ class PNP_SOLVER(object):
     """Same public surface as the reference class (scripts/PNP_SOLVER_LIB.py:7-203)."""
 
     def __init__(self, np_K_camera_est, point_3d_dict_list, pattern_scale_list=None, verbose=False):
-        # reference :10-64
-        self.verbose = True
+        """Reference :10-64: private copies of K and of the golden patterns, one scale per pattern
+        (a short or missing scale list is filled up with 1.0), and the pattern store built from
+        them.  The pre-transform of the reference is switched off there (:27) and here."""
+        self.verbose = verbose
         self.np_K_camera_est = copy.deepcopy(np_K_camera_est)
-        self.pattern_scale_list = pattern_scale_list
         self.point_3d_dict_list = copy.deepcopy(point_3d_dict_list)
-        n_pat = len(self.point_3d_dict_list)
-        if self.pattern_scale_list is None:
-            self.pattern_scale_list = [1.0 for _ in range(n_pat)]
-        elif len(self.pattern_scale_list) < n_pat:
-            self.pattern_scale_list += [1.0 for _ in range(n_pat - len(self.pattern_scale_list))]
+        scales = [] if pattern_scale_list is None else pattern_scale_list
+        scales += [1.0] * (len(self.point_3d_dict_list) - len(scales))     # in place, as the reference pads
+        self.pattern_scale_list = scales
         self.is_using_pre_transform = False
         self.pre_trans_R_a_h = np.eye(3)
-        self.pre_trans_t_a_h = np.array([[0.0, 0.0, -0.5]]).T
+        self.pre_trans_t_a_h = np.array([[0.0], [0.0], [-0.5]])
         self.np_R_c_a_est = np.eye(3)
         self.np_t_c_a_est = np.zeros((3, 1))
-        self.np_point_3d_dict_list = list()
-        self.np_point_3d_pretransfer_dict_list = list()
-        for pattern, scale in zip(self.point_3d_dict_list, self.pattern_scale_list):
-            d, d_pre = self.get_np_point_3d_dict(pattern, scale, self.is_using_pre_transform,
-                                                 self.pre_trans_R_a_h, self.pre_trans_t_a_h)
-            self.np_point_3d_dict_list.append(d)
-            self.np_point_3d_pretransfer_dict_list.append(d_pre)
+        self.np_point_3d_dict_list = [None] * len(self.point_3d_dict_list)
+        self.np_point_3d_pretransfer_dict_list = [None] * len(self.point_3d_dict_list)
+        for i in range(len(self.point_3d_dict_list)):
+            self._store_pattern(i)
         self.set_golden_pattern_id(0)
-        self.verbose = verbose
 
     # ---- pattern store (reference :66-135) ----------------------------------------------
+    def _store_pattern(self, id):
+        """(Re)builds slot `id` of both array-valued pattern lists from the list-valued one."""
+        plain, moved = self.get_np_point_3d_dict(self.point_3d_dict_list[id], self.pattern_scale_list[id],
+                                                 self.is_using_pre_transform, self.pre_trans_R_a_h,
+                                                 self.pre_trans_t_a_h)
+        self.np_point_3d_dict_list[id] = plain
+        self.np_point_3d_pretransfer_dict_list[id] = moved
+
     def set_golden_pattern_id(self, id):
         self.current_golden_pattern_id = id
 
@@ -74,33 +78,22 @@ class PNP_SOLVER(object):
 
     def get_np_point_3d_dict(self, point_3d_dict, pattern_scale, is_using_pre_transform=False,
                              pre_trans_R_a_h=None, pre_trans_t_a_h=None):
-        np_dict = dict()
-        for k in point_3d_dict:
-            np_dict[k] = np.array(point_3d_dict[k]).reshape((3, 1))
-            np_dict[k] *= pattern_scale
-        np_pre = copy.deepcopy(np_dict)
+        """{key: [x, y, z]} -> ({key: (3,1) array * scale}, the same moved by the pre-transform if
+        one is in use, otherwise an independent copy) (reference :75-122)."""
+        plain = {k: np.array(v).reshape((3, 1)) * pattern_scale for k, v in point_3d_dict.items()}
         if is_using_pre_transform:
-            for k in np_pre:
-                np_pre[k] = self.transform_3D_point(np_pre[k], pre_trans_R_a_h, pre_trans_t_a_h)
-        if self.verbose:
-            self.lib_print("-" * 35)
-            self.lib_print("3D points in local coordinate:")
-            self.lib_print("pattern_scale = %f" % pattern_scale)
-            with np.printoptions(suppress=True, precision=4):
-                for k in np_dict:
-                    self.lib_print("%s:%sp_3D=%s.T | p_3D_pretrans=%s.T"
-                                   % (k, " " * (12 - len(k)), str(np_dict[k].T), str(np_pre[k].T)))
-            self.lib_print("-" * 35)
-        return (np_dict, np_pre)
+            moved = {k: self.transform_3D_point(p, pre_trans_R_a_h, pre_trans_t_a_h) for k, p in plain.items()}
+        else:
+            moved = {k: p.copy() for k, p in plain.items()}
+        for k in plain:
+            self.lib_print("pattern point %-12s %s (scale %g)" % (k, plain[k].ravel(), pattern_scale))
+        return (plain, moved)
 
     def update_the_selected_golden_pattern(self, id, point_3d_dict, pattern_scale):
+        """Replaces golden pattern `id` and its scale (reference :124-135)."""
         self.pattern_scale_list[id] = pattern_scale
         self.point_3d_dict_list[id] = copy.deepcopy(point_3d_dict)
-        d, d_pre = self.get_np_point_3d_dict(self.point_3d_dict_list[id], self.pattern_scale_list[id],
-                                             self.is_using_pre_transform, self.pre_trans_R_a_h,
-                                             self.pre_trans_t_a_h)
-        self.np_point_3d_dict_list[id] = d
-        self.np_point_3d_pretransfer_dict_list[id] = d_pre
+        self._store_pattern(id)
         return True
 
     def lib_print(self, str=''):
@@ -108,15 +101,26 @@ class PNP_SOLVER(object):
             print(str)
 
     # ---- dict <-> array glue --------------------------------------------------------------
-    @staticmethod
-    def _image_array(np_point_image_dict, keys):
+    def _image_array(self, np_point_image_dict, keys):
         """(1, N, 2) float64 of [u, v] for `keys`, in that order; a missing key raises
-        KeyError exactly as the reference's dict lookup does (:3270, :3307)."""
+        KeyError exactly as the reference's dict lookup does (:3270, :3307).
+
+        The reference multiplies K^-1 by the whole homogeneous vector [u, v, w] and keeps the
+        first two components undivided (:3307-3309, :3101), so a landmark with w != 1 (w = -1 for
+        a point projected from behind the camera, :4547) is a different measurement from
+        [u, v, 1].  The kernels take [u, v] and imply w = 1; such a landmark is therefore replaced
+        by the pixel [u', v', 1] with the same two components: with M, c the first two rows of
+        K^-1 split into its 2x2 block and its last column, M u' + c = M u + w c."""
         uv = np.empty((1, len(keys), 2), dtype=np.float64)
+        shift = None
         for i, k in enumerate(keys):
             p = np.asarray(np_point_image_dict[k], dtype=np.float64).reshape(-1)
-            uv[0, i, 0] = p[0]
-            uv[0, i, 1] = p[1]
+            uv[0, i] = p[0:2]
+            if p.size > 2 and p[2] != 1.0:
+                if shift is None:
+                    K_inv = np.linalg.inv(np.asarray(self.np_K_camera_est, dtype=np.float64))
+                    shift = np.linalg.solve(K_inv[0:2, 0:2], K_inv[0:2, 2])
+                uv[0, i] += (p[2] - 1.0) * shift
         return uv
 
     @staticmethod
@@ -154,7 +158,15 @@ class PNP_SOLVER(object):
         self.lib_print("--> Best fitted pattern is [%d] with res_norm_n_est = %f"
                        % (idx_best, float(out["res_norm"][0])))
         self.set_golden_pattern_id(idx_best)
-        return self._finish(out)
+        result = self._finish(out)
+        if idx_best != len(patterns) - 1:
+            # the reference's pattern loop leaves np_R_c_a_est / np_t_c_a_est at the estimate of the
+            # pattern it tried LAST (every single-pattern solve overwrites them, :2986-2987), and
+            # random_stress_test.py:353-354 reads them after solve_pnp
+            last = _batch.solve_pnp_batch(uv, patterns[-1], self.np_K_camera_est, method="qeif", want_rpy=False)
+            self.np_R_c_a_est = last["R"][0].astype(np.float64)
+            self.np_t_c_a_est = last["t"][0].astype(np.float64).reshape((3, 1))
+        return result
 
     def solve_pnp_QEIF_single_pattern(self, np_point_image_dict, np_point_3d_pretransfer_dict, LM_key_list=None):
         """Reference :2771-3025.  LM_key_list=None uses every key of the pattern dict, in its
@@ -199,83 +211,41 @@ class PNP_SOLVER(object):
         return _batch.solve_pnp_batch(uv, xyz, self.np_K_camera_est, method=method, params=params,
                                       num_it=num_it, want_rpy=want_rpy)
 
-    # ---- Euler / projection utilities (host side, reference :4442-4621, :4666-4675) ---------
+    # ---- Euler / projection utilities (host side; conventions in _geometry.py) ----------------
     def get_rotation_matrix_from_Euler(self, roll, yaw, pitch, is_degree=False):
-        yaw = -yaw
-        if is_degree:
-            roll, yaw, pitch = np.deg2rad(roll), np.deg2rad(yaw), np.deg2rad(pitch)
-        c1, s1 = np.cos(roll), np.sin(roll)
-        c2, s2 = np.cos(yaw), np.sin(yaw)
-        c3, s3 = np.cos(pitch), np.sin(pitch)
-        E_roll = np.array([[c1, s1, 0.0], [-s1, c1, 0.0], [0.0, 0.0, 1.0]])
-        E_yaw = np.array([[c2, 0.0, -s2], [0.0, 1.0, 0.0], [s2, 0.0, c2]])
-        E_pitch = np.array([[1.0, 0.0, 0.0], [0.0, c3, s3], [0.0, -s3, c3]])
-        return E_roll @ E_pitch @ E_yaw
+        """Reference :4442-4472."""
+        return _geo.rotation_from_euler(roll, yaw, pitch, is_degree)
 
     def get_Euler_from_rotation_matrix(self, R_in, verbose=True, is_degree=False):
-        eps = 10.0 ** -7
-        if np.abs(np.pi / 2.0 - np.arcsin(np.abs(R_in[2, 1]))) <= eps:
-            theta_2 = np.sign(-R_in[2, 1]) * (np.pi / 2.0)
-            theta_3 = 0.0
-            theta_1 = np.arctan2(-R_in[1, 0], R_in[0, 0])
-        else:
-            theta_1 = np.arctan2(R_in[0, 1], R_in[1, 1])
-            theta_3 = np.arctan2(R_in[2, 0], R_in[2, 2])
-            c1, c3 = np.cos(theta_1), np.cos(theta_3)
-            if np.abs(c1) > np.abs(c3):
-                if verbose:
-                    self.lib_print("Set c2 as (r22/c1)")
-                c2 = R_in[1, 1] / c1
-            else:
-                if verbose:
-                    self.lib_print("Set c2 as (r33/c3)")
-                c2 = R_in[2, 2] / c3
-            theta_2 = np.arctan2(-R_in[2, 1], c2)
-        roll, pitch, yaw = theta_1, theta_2, theta_3
-        if is_degree:
-            roll, yaw, pitch = np.rad2deg(roll), np.rad2deg(yaw), np.rad2deg(pitch)
-        yaw = -yaw
-        return (roll, yaw, pitch)
+        """Reference :4474-4517; returns (roll, yaw, pitch).  `verbose` only gated a debug print."""
+        return _geo.euler_from_rotation(R_in, is_degree)
 
     def transform_3D_point(self, point_3D, R_in, t_in):
-        return (R_in @ point_3D + t_in)
+        return R_in @ point_3D + t_in
 
     def perspective_projection(self, np_point_3d, np_K_camera, np_R, np_t, is_quantized=False,
                                quantize_q=1.0, is_returning_homogeneous_vec=True):
-        _p = np_point_3d.reshape((3, 1))
-        _ray = np_K_camera @ (np_R @ _p + np_t)
-        projection_no_q = _ray / abs(_ray[2, 0])
-        if is_quantized:
-            np_point_image = np.around(projection_no_q / quantize_q) * quantize_q
-        else:
-            np_point_image = projection_no_q
-        if is_returning_homogeneous_vec:
-            return (np_point_image, projection_no_q)
-        return (np_point_image[0:2, 0], projection_no_q[0:2, 0])
+        """Reference :4532-4557: (pixel, unquantised pixel) as (3,1) homogeneous vectors or, with
+        is_returning_homogeneous_vec=False, as their first two components."""
+        pair = _geo.pinhole(np_point_3d, np_K_camera, np_R, np_t, quantize_q if is_quantized else None)
+        return pair if is_returning_homogeneous_vec else tuple(v[0:2, 0] for v in pair)
 
     def perspective_projection_obj_axis(self, np_R, np_t, scale=1.0):
-        K = self.np_K_camera_est
-        kw = dict(is_quantized=False, is_returning_homogeneous_vec=False)
-        uv_o, _ = self.perspective_projection(np.array([[0.0, 0.0, 0.0]]), K, np_R, np_t, **kw)
-        uv_x1, _ = self.perspective_projection(np.array([[scale, 0.0, 0.0]]), K, np_R, np_t, **kw)
-        uv_y1, _ = self.perspective_projection(np.array([[0.0, scale, 0.0]]), K, np_R, np_t, **kw)
-        uv_z1, _ = self.perspective_projection(np.array([[0.0, 0.0, scale]]), K, np_R, np_t, **kw)
-        return (uv_o, (uv_x1 - uv_o), (uv_y1 - uv_o), (uv_z1 - uv_o))
+        """Reference :4560-4583: pixel of the pattern origin and the pixel offsets of the three
+        axis tips `scale` away from it."""
+        tips = np.vstack([np.zeros((1, 3)), scale * np.eye(3)])
+        px = [_geo.pinhole(p, self.np_K_camera_est, np_R, np_t)[0][0:2, 0] for p in tips]
+        return (px[0], px[1] - px[0], px[2] - px[0], px[3] - px[0])
 
     def perspective_projection_golden_landmarks(self, np_R, np_t, is_quantized=False, quantize_q=1.0,
                                                 is_pretrans_points=False, is_returning_homogeneous_vec=True):
-        src = (self.get_current_pretransfered_golden_pattern() if is_pretrans_points
-               else self.get_current_golden_pattern())
-        np_point_image_dict = dict()
-        for k in src:
-            img, _ = self.perspective_projection(src[k], self.np_K_camera_est, np_R, np_t,
-                                                 is_quantized=is_quantized, quantize_q=quantize_q,
-                                                 is_returning_homogeneous_vec=is_returning_homogeneous_vec)
-            np_point_image_dict[k] = img
-        return np_point_image_dict
+        """Reference :4586-4621: {key: pixel} of the selected golden pattern under (np_R, np_t)."""
+        points = (self.get_current_pretransfered_golden_pattern() if is_pretrans_points
+                  else self.get_current_golden_pattern())
+        return {k: self.perspective_projection(p, self.np_K_camera_est, np_R, np_t, is_quantized, quantize_q,
+                                               is_returning_homogeneous_vec)[0]
+                for k, p in points.items()}
 
     def unit_vec(self, vec_in):
-        _norm = np.linalg.norm(vec_in)
-        _eps = 10 ** -7
-        _norm_inv = 1 / _eps if np.abs(_norm) <= 10 ** -7 else 1.0 / _norm
-        return (vec_in * _norm_inv)
+        """Reference :4666-4675."""
+        return _geo.unit(vec_in)

@@ -508,8 +508,30 @@ def test_dropin_two_patterns(golden, torch_dev):
         R, t, *_ = s.solve_pnp(img_dict(g["uv"][i].astype(np.float64), po.LM6_KEYS))
         assert s.current_golden_pattern_id == g["pattern_id"][i]
         assert rot_angle(R, g["R"][i])[0] <= ANG_TOL
+        # the estimate attributes are those of the pattern tried last, whichever fitted best
+        # (every single-pattern solve of the reference's loop overwrites them)
+        last = po.qeif_solve(g["uv"][i].astype(np.float64), po.pattern_array(po.PATTERN_HOLLY, po.LM6_KEYS), K)
+        assert np.abs(s.np_R_c_a_est - last["R"]).max() <= 1e-9
+        assert np.abs(s.np_t_c_a_est[:, 0] - last["t"]).max() <= 1e-9
+    assert len(set(g["pattern_id"][:30].tolist())) == 2          # both outcomes occurred above
     out = s.solve_pnp_batch(g["uv"], all_patterns=True)
     assert np.array_equal(out["pattern_id"], g["pattern_id"])
+
+
+def test_dropin_homogeneous_component_is_honoured(golden, torch_dev):
+    """The reference forms K^-1 [u, v, w] with the dict's own third component (w = -1 for a
+    landmark projected from behind the camera) and does not divide by it."""
+    g = golden("stress_qeif_n6")
+    uv = g["uv15"][3, lm6_indices(g), :].astype(np.float64)
+    w = np.array([1.0, -1.0, 1.0, 1.0, 0.5, 1.0])
+    img = {k: np.array([[uv[i, 0]], [uv[i, 1]], [w[i]]]) for i, k in enumerate(po.LM6_KEYS)}
+    s = pnp.PNP_SOLVER(K, [po.PATTERN_ALEXANDER])
+    R, t, t3, roll, yaw, pitch, res = s.solve_pnp(img)
+    ref = po.qeif_solve(np.column_stack([uv, w]), P6, K)
+    plain = po.qeif_solve(uv, P6, K)
+    assert np.abs(ref["R"] - plain["R"]).max() > 1e-2           # w matters
+    assert np.abs(R - ref["R"]).max() <= 1e-8 and np.abs(t[:, 0] - ref["t"]).max() <= 1e-8 * abs(ref["t3"])
+    assert abs(res - ref["res_norm"]) <= 1e-9 * max(1.0, ref["res_norm"])
 
 
 def test_dropin_named_solvers(golden, torch_dev):

@@ -161,6 +161,17 @@ def test_dict_to_array_glue(golden):
     uv = s._image_array(img, pnp.LM_KEY_LIST)
     assert uv.dtype == np.float64 and uv.shape == (1, 6, 2)      # the reference's dtype, unrounded
     assert np.array_equal(uv[0], g["uv15"][lm6_indices(g)])
+    # a homogeneous component other than 1 is folded into the pixel: K^-1 [u', v', 1] has the first
+    # two components of K^-1 [u, v, w]
+    K2 = np.array([[230.0, 1.5, 161.0], [0.0, 226.0, 119.0], [0.0, 0.0, 1.0]])
+    s2 = pnp.PNP_SOLVER(K2, [po.PATTERN_ALEXANDER])
+    img2 = dict(img)
+    img2["eye_r_97"] = np.array([[100.0], [50.0], [-1.0]])
+    uv2 = s2._image_array(img2, pnp.LM_KEY_LIST)
+    Ki = np.linalg.inv(K2)
+    assert np.allclose(Ki[0:2] @ np.array([uv2[0, 1, 0], uv2[0, 1, 1], 1.0]), Ki[0:2] @ np.array([100.0, 50.0, -1.0]),
+                       rtol=0, atol=1e-15)
+    assert np.array_equal(uv2[0, 0], uv[0, 0]) and np.array_equal(uv2[0, 2:], uv[0, 2:])
     P = s._pattern_array(s.np_point_3d_pretransfer_dict_list[0], pnp.LM_KEY_LIST)
     assert P.dtype == np.float64
     assert np.array_equal(P, po.pattern_array(po.PATTERN_ALEXANDER, po.LM6_KEYS))
