@@ -95,7 +95,7 @@ def main():
     ap.add_argument('--ref', default='/root/reference/scripts')
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
     ap.add_argument('--n-stress', type=int, default=10000)
-    ap.add_argument('--only', default='', help='comma-separated section numbers (1-12); default all')
+    ap.add_argument('--only', default='', help='comma-separated section numbers (1-13); default all')
     args = ap.parse_args()
     out_dir = os.path.abspath(args.out)
     os.makedirs(out_dir, exist_ok=True)
@@ -503,6 +503,55 @@ def main():
                 tops['top_idx_' + q] = np.array([heapq.heappop(heaps[q])[1] for _ in range(n_top)], dtype=np.int64)
             save('face_variation_%s.npz' % tag, seed=np.int64(42), keys15=np.array(keys15), perturbation=pert,
                  poses=poses, uv15=uv15.astype(np.float32), abs_err=abs_err, **tops, **pack(res))
+
+    # ---- 13. iterated DLT on planar patterns: the (2N x 8) system is rank-deficient and the
+    #          reference's pinv (:293) returns its minimum-norm solution --------------------------
+    if want(13):
+        import contextlib
+        import io
+        sink = io.StringIO()
+        n_per = 192
+        kinds = ('z_zero', 'z_const', 'tilted')
+        # coordinates on a grid of 2^-10 m and planes with dyadic coefficients, so that every
+        # coordinate is exact in float32 and the float32 device path sees the same planar pattern
+        grid = {k: [round(c * 1024.0) / 1024.0 for c in alex[k]] for k in LM6}
+        pats = []
+        for kind in kinds:
+            pat = {}
+            for k in LM6:
+                x, y, _ = grid[k]
+                z = 0.0 if kind == 'z_zero' else (2.0 ** -7 if kind == 'z_const' else 0.25 * x + 0.5 * y)
+                pat[k] = [x, y, z]
+            pats.append(pat)
+        rng = np.random.default_rng(48)
+        uv = np.zeros((len(kinds) * n_per, 6, 2), dtype=np.float32)
+        xyz = np.zeros((len(kinds) * n_per, 6, 3))
+        kind_id = np.zeros(len(kinds) * n_per, dtype=np.int32)
+        raised = np.zeros(len(kinds) * n_per, dtype=bool)
+        res = []
+        for c, pat in enumerate(pats):
+            with contextlib.redirect_stdout(sink):
+                gtp = PNPS.PNP_SOLVER(K, [pat], verbose=False)
+                estp = PNPS.PNP_SOLVER(K, [pat], verbose=False)
+            for j in range(n_per):
+                i = c * n_per + j
+                roll, pitch, yaw, t = draw_stress_pose(rng)
+                if j % 2:
+                    t[0, 0] = t[1, 0] = 0.0
+                R = gtp.get_rotation_matrix_from_Euler(roll, yaw, pitch, is_degree=True)
+                img = gtp.perspective_projection_golden_landmarks(R, t, is_quantized=True)
+                uv[i] = dict_to_uv(img, LM6).astype(np.float32)
+                xyz[i] = np.array([pat[k] for k in LM6])
+                kind_id[i] = c
+                try:
+                    res.append(estp.solve_pnp_single_pattern(uv_to_dict(uv[i].astype(np.float64), LM6),
+                                                             estp.np_point_3d_pretransfer_dict_list[0]))
+                except np.linalg.LinAlgError:
+                    raised[i] = True
+                    nan = np.float64('nan')
+                    res.append((np.full((3, 3), nan), np.full((3, 1), nan), nan, nan, nan, nan, nan))
+        save('dlt_planar.npz', seed=np.int64(48), kinds=np.array(kinds), kind_id=kind_id, uv=uv, xyz=xyz,
+             keys=np.array(LM6), raised=raised, **pack(res))
 
     print('done in %.0f s; numpy %s' % (time.time() - t_start, np.__version__))
 

@@ -247,10 +247,12 @@ def qeif_solve(uv, P, K=K_DEFAULT, **params):
 # Iterated linear DLT with closed-form block reconstruction
 # ---------------------------------------------------------------------------
 
-def dlt_block_reconstruction(phi):
+def dlt_block_reconstruction(phi, se_force=0):
     """Closed-form (R, t, t3) from phi = [phi1(3), phi2(3), delta1, delta2] using only the
     top-left 2x2 block of Gamma = R/t3 (:4158-4364).  Also returns the two quantities whose
-    signs steer the branches: k2 (:4233) and the similarity dot product (:4262)."""
+    signs steer the branches: k2 (:4233) and the similarity dot product (:4262).  se_force = +-1
+    imposes the sign the similarity would pick (test use: with a pattern in the z = 0 plane the
+    similarity is an exact zero and the reference's choice rides on round-off)."""
     phi1, phi2 = phi[0:3], phi[3:6]
     K2 = np.array([[phi1[0], phi1[1]], [phi2[0], phi2[1]]])
     KTK = K2.T @ K2
@@ -266,6 +268,8 @@ def dlt_block_reconstruction(phi):
     alpha_se = -(c * delta_se)
     similarity = alpha_se.dot(np.array([phi1[2], phi2[2]]))
     se = -1.0 if similarity < 0.0 else 1.0
+    if se_force:
+        se = float(se_force)
     alpha, beta = se * alpha_se, se * beta_se
     G = np.array([[K2[0, 0], K2[0, 1], alpha[0]],
                   [K2[1, 0], K2[1, 1], alpha[1]],
@@ -276,12 +280,13 @@ def dlt_block_reconstruction(phi):
     return R, t, t3, k2, similarity
 
 
-def dlt_solve(uv, P, K=K_DEFAULT, num_it=3):
+def dlt_solve(uv, P, K=K_DEFAULT, num_it=3, se_override=None):
     """Iterated linear DLT (:205-430): `num_it` rounds of  Delta_i = theta_i.phi3 + 1
     (clamped, :3031-3046), A (2N,8) with x/y rows interleaved (:3048-3092), phi = pinv(A) B
     (:293), block reconstruction (:366), phi3 <- R[2,:]/t3 (:4002-4017), and the residual of
     the reconstructed pose (:372-380).  The closing reconstruction (:403) repeats the last
-    in-loop one exactly (it does not read phi3), so it is not recomputed."""
+    in-loop one exactly (it does not read phi3), so it is not recomputed.  se_override: one
+    forced mirror sign (+1 / -1, 0 = as computed) per round, see dlt_block_reconstruction."""
     P = np.asarray(P, dtype=np.float64)
     n = P.shape[0]
     Bx, By = normalized_xy(uv, K)
@@ -291,7 +296,7 @@ def dlt_solve(uv, P, K=K_DEFAULT, num_it=3):
     min_abs_k2 = np.inf
     min_abs_sim = np.inf
     min_abs_delta = np.inf
-    for _ in range(num_it):
+    for rnd in range(num_it):
         Delta = P @ phi3 + 1.0
         eps = 10 ** -7
         small = np.abs(Delta) <= eps
@@ -303,7 +308,7 @@ def dlt_solve(uv, P, K=K_DEFAULT, num_it=3):
         A[1::2, 3:6] = P / Delta[:, None]
         A[1::2, 7] = 1.0 / Delta                                       # :3057-3061
         phi = np.linalg.pinv(A) @ B                                    # :293
-        R, t, t3, k2, sim = dlt_block_reconstruction(phi)
+        R, t, t3, k2, sim = dlt_block_reconstruction(phi, se_override[rnd] if se_override else 0)
         min_abs_k2 = min(min_abs_k2, abs(k2))
         min_abs_sim = min(min_abs_sim, abs(sim))
         phi3 = R[2, :] / t3                                            # :4006-4010

@@ -14,14 +14,20 @@ constexpr int kBlock = 256;  // threads per workgroup of the element-wise kernel
 // Two wavefronts per workgroup: a workgroup's slots free up when its slower wavefront ends, so
 // small workgroups keep the SIMDs fuller through the spread of iteration counts than the 256
 // threads the moment kernel wants for its staging geometry.
+#ifndef PNP_SOLVE_BLOCK_BYTES
+#define PNP_SOLVE_BLOCK_BYTES 512
+#endif
 template <typename T>
-constexpr int kSolveBlock = 512 / static_cast<int>(sizeof(T));
+constexpr int kSolveBlock = PNP_SOLVE_BLOCK_BYTES / static_cast<int>(sizeof(T));
 // Threads per workgroup of the moment-form kernel: 256 for float, 128 for double.
 template <typename T>
 constexpr int kMomentBlock = 1024 / static_cast<int>(sizeof(T));
 
 #ifndef PNP_QEIF_WAVES
 #define PNP_QEIF_WAVES 2  // minimum resident waves per SIMD the QEIF kernels are compiled for
+#endif
+#ifndef PNP_DLT_WAVES
+#define PNP_DLT_WAVES 3   // the same for the DLT kernels
 #endif
 
 struct KinvRows {  // first two rows of K^-1: nu_x = a00 u + a01 v + a02, nu_y = a10 u + a11 v + a12
@@ -168,16 +174,23 @@ __device__ __forceinline__ void spd_solve1(const double (&m)[n * (n + 1) / 2], d
 }
 
 // Solves M x = b1 and M x = b2 for a packed SPD n x n matrix (LDL^T, two right-hand sides).
+// Returns whether every pivot was sound: larger than pivot_tol times its own diagonal entry (the
+// ratio is the share of that column not explained by the columns before it, 1 for independent
+// columns).  A pivot that is not (zero, or round-off of either sign) means the matrix is
+// rank-deficient to working precision and the solution just computed is not to be used.  NaN
+// pivots count as sound: NaN input is not rank deficiency, and its NaN solution stands.
 template <int n>
-__device__ __forceinline__ void spd_solve2(const double (&m)[n * (n + 1) / 2], double (&b1)[n],
-                                           double (&b2)[n])
+__device__ __forceinline__ bool spd_solve2(const double (&m)[n * (n + 1) / 2], double (&b1)[n],
+                                           double (&b2)[n], double pivot_tol)
 {
     double L[n][n], W[n][n], dinv[n];
+    bool sound = true;
 #pragma unroll
     for (int j = 0; j < n; ++j) {
         double s = m[tri(j, j)];
 #pragma unroll
         for (int k = 0; k < j; ++k) s = __builtin_fma(-W[j][k], L[j][k], s);
+        sound = sound && !(s <= pivot_tol * m[tri(j, j)]);  // a NaN pivot is not a rank verdict
         dinv[j] = rcp(s);
 #pragma unroll
         for (int i = j + 1; i < n; ++i) {
@@ -208,6 +221,116 @@ __device__ __forceinline__ void spd_solve2(const double (&m)[n * (n + 1) / 2], d
             b1[i] = __builtin_fma(-L[k][i], b1[k], b1[i]);
             b2[i] = __builtin_fma(-L[k][i], b2[k], b2[i]);
         }
+    }
+    return sound;
+}
+
+// One Jacobi rotation of the symmetric n x n matrix S (full storage) in the (p,q) plane,
+// accumulated into V (whose columns become the eigenvectors).  An off-diagonal entry below
+// 2^-60 of the geometric mean of its two diagonal entries is set to zero instead (the rotation
+// would change nothing at working precision); that also bounds theta, so that the refined
+// hardware reciprocal and square root stay within their range.  Returns whether it rotated.
+template <int n, int p, int q>
+__device__ __forceinline__ bool jacobi_rotate(double (&S)[n][n], double (&V)[n][n])
+{
+    const double apq = S[p][q];
+    if (apq == 0.0) return false;
+    if (apq * apq <= 0x1p-120 * fabs(S[p][p] * S[q][q])) {
+        S[p][q] = S[q][p] = 0.0;
+        return false;
+    }
+    const double theta = 0.5 * (S[q][q] - S[p][p]) * rcp(apq);
+    const double tt = __builtin_copysign(rcp(fabs(theta) + sqrt_pos(__builtin_fma(theta, theta, 1.0))), theta);
+    const double c = rcp(sqrt_pos(__builtin_fma(tt, tt, 1.0))), s = tt * c;
+    S[p][p] -= tt * apq;
+    S[q][q] += tt * apq;
+    S[p][q] = S[q][p] = 0.0;
+#pragma unroll
+    for (int r = 0; r < n; ++r) {
+        if (r == p || r == q) continue;
+        const double arp = S[r][p], arq = S[r][q];
+        S[r][p] = S[p][r] = c * arp - s * arq;
+        S[r][q] = S[q][r] = s * arp + c * arq;
+    }
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+        const double vkp = V[k][p], vkq = V[k][q];
+        V[k][p] = c * vkp - s * vkq;
+        V[k][q] = s * vkp + c * vkq;
+    }
+    return true;
+}
+
+template <int n, int p, int q>
+__device__ __forceinline__ bool jacobi_sweep_from(double (&S)[n][n], double (&V)[n][n])
+{
+    bool rotated = jacobi_rotate<n, p, q>(S, V);
+    if constexpr (q + 1 < n)
+        rotated = jacobi_sweep_from<n, p, q + 1>(S, V) || rotated;
+    else if constexpr (p + 2 < n)
+        rotated = jacobi_sweep_from<n, p + 1, p + 2>(S, V) || rotated;
+    return rotated;
+}
+
+// Diagonalises S = V diag(lambda) V^T by cyclic sweeps, at most max_sweeps of them and until a
+// sweep finds nothing left to rotate (S ends up diagonal; V must come in as the identity).
+// Quadratically convergent: five or six sweeps reach round-off for n <= 4.
+template <int n>
+__device__ __forceinline__ void jacobi_eigen(double (&S)[n][n], double (&V)[n][n], int max_sweeps)
+{
+#pragma unroll 1
+    for (int sw = 0; sw < max_sweeps; ++sw)
+        if (!jacobi_sweep_from<n, 0, 1>(S, V)) break;
+}
+
+// x = M^+ b for two right-hand sides, M a packed symmetric positive semi-definite n x n matrix
+// and M^+ its pseudo-inverse: eigenvalues not above rank_tol times the largest are taken as
+// zero and their directions left out, which yields the minimum-norm least-squares solution, as
+// numpy.linalg.pinv does for the rectangular system M was formed from.  (Forming M squares the
+// singular values and adds round-off of about 1e-16 of the largest eigenvalue, so a singular
+// value below sqrt(rank_tol) of the largest counts as zero here.)  NaN in M reaches x.
+template <int n>
+__device__ __forceinline__ void sym_pinv_solve2(const double (&m)[n * (n + 1) / 2], double (&b1)[n],
+                                                double (&b2)[n], double rank_tol)
+{
+    double S[n][n], V[n][n];
+#pragma unroll
+    for (int i = 0; i < n; ++i)
+#pragma unroll
+        for (int j = 0; j < n; ++j) {
+            S[i][j] = m[i >= j ? tri(i, j) : tri(j, i)];
+            V[i][j] = (i == j) ? 1.0 : 0.0;
+        }
+    jacobi_eigen<n>(S, V, 12);
+    double lam_max = S[0][0];
+#pragma unroll
+    for (int k = 1; k < n; ++k) lam_max = (S[k][k] > lam_max) ? S[k][k] : lam_max;
+    const double cut = rank_tol * lam_max;
+    double x1[n], x2[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) x1[i] = x2[i] = 0.0;
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+        if (S[k][k] <= cut) continue;  // a NaN eigenvalue is kept, and spreads
+        double c1 = 0.0, c2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            c1 = __builtin_fma(V[i][k], b1[i], c1);
+            c2 = __builtin_fma(V[i][k], b2[i], c2);
+        }
+        const double inv = rcp(S[k][k]);
+        c1 *= inv;
+        c2 *= inv;
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            x1[i] = __builtin_fma(V[i][k], c1, x1[i]);
+            x2[i] = __builtin_fma(V[i][k], c2, x2[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+        b1[i] = x1[i];
+        b2[i] = x2[i];
     }
 }
 

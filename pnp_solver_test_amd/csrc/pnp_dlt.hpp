@@ -51,26 +51,46 @@ __device__ __forceinline__ void dlt_block_reconstruct(const double (&f)[8], doub
     t[2] = gi;
 }
 
-// Delta_i = theta_i . phi3 + 1, kept away from zero by +-1e-7
-__device__ __forceinline__ double dlt_depth_factor(double X, double Y, double Z, const double (&phi3)[3])
+// Delta_i = theta_i . phi3 + 1 is kept away from zero by +-1e-7
+// (Dl is never -0: a sum that cancels exactly rounds to +0)
+__device__ __forceinline__ double dlt_clamp_depth(double Dl)
 {
-    const double Dl = __builtin_fma(X, phi3[0], __builtin_fma(Y, phi3[1], __builtin_fma(Z, phi3[2], 1.0)));
-    // (Dl is never -0: a sum that cancels exactly rounds to +0)
     return (fabs(Dl) <= 1e-7) ? __builtin_copysign(1e-7, Dl) : Dl;
 }
+
+// Relative size below which a pivot of the 4x4 normal equations counts as zero (see spd_solve2),
+// and relative size below which one of their eigenvalues does (see sym_pinv_solve2).  Face-like
+// patterns have pivot ratios above 1e-6 and eigenvalue ratios above 1e-5 in every round of the
+// random-stress distribution; a planar pattern has one pivot and one eigenvalue at round-off
+// (about 1e-15 of the largest, or exactly 0).  Between the pivot tolerance and round-off the
+// LDL^T solution is as good as any that starts from the normal equations, so the tolerance sits
+// just above round-off: a problem sent down the pseudo-inverse path costs its wavefront about
+// twenty times a normal solve, and one such straggler lengthens the whole launch.
+#ifndef PNP_DLT_PIVOT_TOL
+#define PNP_DLT_PIVOT_TOL 1e-12
+#endif
+constexpr double kDltPivotTol = PNP_DLT_PIVOT_TOL;
+constexpr double kDltRankTol = 1e-13;
 
 // One problem's DLT solve.  The reference's (2N x 8) system A phi = B has x rows that touch
 // only columns {0,1,2,6} and y rows that touch only {3,4,5,7}, with the same coefficients
 // d_i = [theta_i/Delta_i, 1/Delta_i]: it is two (N x 4) least-squares problems sharing one
 // matrix, solved here through the 4x4 normal equations M = sum d d^T with two right-hand
 // sides.  Equal to pinv(A) B for a full-rank system.
-template <int LPI, int NCT, typename PointFetch>
-__device__ __forceinline__ void dlt_solve(const PointFetch &pts, int N, int lane_in_group,
+//
+// A rank-deficient system (a planar pattern, fewer than four points) has no unique solution; the
+// reference's pinv returns the one of minimum norm.  PINV = false solves M by LDL^T and returns
+// false if any round met a pivot at round-off, in which case its outputs are not to be used;
+// PINV = true solves every round through the pseudo-inverse of M and always returns true.  The
+// kernels run the first and repeat a problem with the second only when the first gives up.
+template <int LPI, int NCT, bool PINV, typename PointFetch>
+__device__ __forceinline__ bool dlt_solve(const PointFetch &pts, int N, int lane_in_group,
                                           int num_it, double (&R)[9], double (&t)[3],
                                           double &res_out)
 {
     double phi3[3] = {0.0, 0.0, 1.0};
     double gam = 0.0, res = 30.0;  // gam = gamma = 1/t3
+    bool sound = true;
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = 0.0;
     t[0] = t[1] = t[2] = 0.0;
@@ -92,21 +112,30 @@ __device__ __forceinline__ void dlt_solve(const PointFetch &pts, int N, int lane
                 ry[a] = __builtin_fma(d[a], by, ry[a]);
             }
         };
-        auto depth = [&](int i) {
+        auto raw_depth = [&](int i) {
             double X, Y, Z, bx, by;
             pts(i, X, Y, Z, bx, by);
-            return dlt_depth_factor(X, Y, Z, phi3);
+            return __builtin_fma(X, phi3[0], __builtin_fma(Y, phi3[1], __builtin_fma(Z, phi3[2], 1.0)));
         };
         double wts[NCT > 0 ? NCT : 1];
         if constexpr (NCT > 0) {
             // 1/Delta_i of all NCT points from one reciprocal (of their product) and 3 (NCT - 1)
-            // multiplications; the factors are clamped away from zero and of order one
+            // multiplications; the factors are clamped away from zero and of order one.  The clamp
+            // is applied only when the smallest |Delta_i| calls for it (one test per round, not
+            // one per point).
             double D[NCT], pre[NCT];
+            double smallest = 1.0;
 #pragma unroll
             for (int i = 0; i < NCT; ++i) {
-                D[i] = depth(i);
-                pre[i] = (i == 0) ? D[0] : pre[i - 1] * D[i];
+                D[i] = raw_depth(i);
+                smallest = fmin(smallest, fabs(D[i]));
             }
+            if (smallest <= 1e-7) {
+#pragma unroll
+                for (int i = 0; i < NCT; ++i) D[i] = dlt_clamp_depth(D[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < NCT; ++i) pre[i] = (i == 0) ? D[0] : pre[i - 1] * D[i];
             double inv = rcp(pre[NCT - 1]);
 #pragma unroll
             for (int i = NCT - 1; i > 0; --i) {
@@ -117,7 +146,7 @@ __device__ __forceinline__ void dlt_solve(const PointFetch &pts, int N, int lane
 #pragma unroll
             for (int i = 0; i < NCT; ++i) add_row(i, wts[i]);
         } else {
-            for (int i = lane_in_group; i < N; i += LPI) add_row(i, rcp(depth(i)));
+            for (int i = lane_in_group; i < N; i += LPI) add_row(i, rcp(dlt_clamp_depth(raw_depth(i))));
         }
         if (LPI > 1) {
 #pragma unroll
@@ -128,7 +157,10 @@ __device__ __forceinline__ void dlt_solve(const PointFetch &pts, int N, int lane
                 ry[i] = group_sum<LPI>(ry[i]);
             }
         }
-        spd_solve2<4>(M, rx, ry);
+        if constexpr (PINV)
+            sym_pinv_solve2<4>(M, rx, ry, kDltRankTol);
+        else
+            sound = spd_solve2<4>(M, rx, ry, kDltPivotTol) && sound;
         const double f[8] = {rx[0], rx[1], rx[2], ry[0], ry[1], ry[2], rx[3], ry[3]};
         dlt_block_reconstruct(f, R, t, gam);
         if (it == num_it - 1) {
@@ -139,7 +171,7 @@ __device__ __forceinline__ void dlt_solve(const PointFetch &pts, int N, int lane
             auto residual = [&](int i) {
                 double X, Y, Z, bx, by;
                 pts(i, X, Y, Z, bx, by);
-                const double w = (NCT > 0) ? wts[NCT > 0 ? i : 0] : rcp(dlt_depth_factor(X, Y, Z, phi3));
+                const double w = (NCT > 0) ? wts[NCT > 0 ? i : 0] : rcp(dlt_clamp_depth(raw_depth(i)));
                 const double ex = bx - w * __builtin_fma(X, fx[0], __builtin_fma(Y, fx[1], __builtin_fma(Z, fx[2], fx[3])));
                 const double ey = by - w * __builtin_fma(X, fy[0], __builtin_fma(Y, fy[1], __builtin_fma(Z, fy[2], fy[3])));
                 ss = __builtin_fma(ex, ex, __builtin_fma(ey, ey, ss));
@@ -152,12 +184,14 @@ __device__ __forceinline__ void dlt_solve(const PointFetch &pts, int N, int lane
             }
             if (LPI > 1) ss = group_sum<LPI>(ss);
             res = sqrt_pos(ss);
+        } else {
+            phi3[0] = R[6] * gam;  // phi3 = R[2,:] / t3, for the next round
+            phi3[1] = R[7] * gam;
+            phi3[2] = R[8] * gam;
         }
-        phi3[0] = R[6] * gam;  // phi3 = R[2,:] / t3
-        phi3[1] = R[7] * gam;
-        phi3[2] = R[8] * gam;
     }
     res_out = res;
+    return sound;
 }
 
 }  // namespace pnp

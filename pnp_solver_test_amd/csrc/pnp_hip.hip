@@ -153,7 +153,7 @@ int kinv_rows(const double K[9], pnp::KinvRows &ki)
 
 size_t lds_bytes(int lpi, int N, bool per_problem_xyz, int n_patterns, size_t elem)
 {
-    const size_t pb = (512 / elem) / lpi;   // pnp::kSolveBlock<T> / lpi
+    const size_t pb = (PNP_SOLVE_BLOCK_BYTES / elem) / lpi;   // pnp::kSolveBlock<T> / lpi
     const size_t uv = pb * 2 * N;
     const size_t xyz = per_problem_xyz ? pb * 3 * N : static_cast<size_t>(n_patterns) * 3 * N;
     return (uv + xyz) * elem;

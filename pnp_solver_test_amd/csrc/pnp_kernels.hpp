@@ -389,18 +389,28 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_QEIF_WAVES) void qeif_moment_k
 }
 
 template <int LPI, int NCT, typename T>
-__global__ __launch_bounds__(kSolveBlock<T>) void dlt_kernel(
+__global__ __launch_bounds__(kSolveBlock<T>, PNP_DLT_WAVES) void dlt_kernel(
     const T *__restrict__ uv, const T *__restrict__ xyz, int64_t xyz_stride, KinvRows ki, int64_t B, int N,
     int num_it, T *__restrict__ R_out, T *__restrict__ t_out, T *__restrict__ res_out, T *__restrict__ rpy_out)
 {
     const Slot<T> s = stage_problems<LPI, kSolveBlock<T>>(uv, xyz, xyz_stride, 1, ki, B, N);
     double R[9], t[3], res;
+    bool sound;
     if constexpr (NCT > 0) {
         const RegPoints<NCT> rp(s.pts);
-        dlt_solve<1, NCT>(rp, N, 0, num_it, R, t, res);
+        sound = dlt_solve<1, NCT, false>(rp, N, 0, num_it, R, t, res);
     } else {
-        dlt_solve<LPI, 0>(s.pts, N, s.lane_in_group, num_it, R, t, res);
+        sound = dlt_solve<LPI, 0, false>(s.pts, N, s.lane_in_group, num_it, R, t, res);
     }
+    // A problem whose normal equations were rank-deficient in some round (planar pattern, fewer
+    // than four points) is solved again through the pseudo-inverse, from the points in LDS; the
+    // registers of the first attempt are dead by now, so the rare path costs the common one none.
+#ifndef PNP_DLT_NO_PINV
+    if (!sound) dlt_solve<LPI, 0, true>(s.pts, N, s.lane_in_group, num_it, R, t, res);
+#endif
+#ifdef PNP_DLT_DEBUG_MARK
+    if (!sound) res = -1.0;
+#endif
     if (s.store) {
         store_pose(s.problem, R, t, R_out, t_out);
         if (res_out) res_out[s.problem] = static_cast<T>(res);

@@ -58,33 +58,6 @@ __device__ __forceinline__ void ldlt_solve_inplace(double (&A)[n * (n + 1) / 2],
     }
 }
 
-// One Jacobi rotation of the symmetric 3x3 matrix S (full storage) in the (p,q) plane,
-// accumulated into V (columns are the eigenvectors).
-template <int p, int q>
-__device__ __forceinline__ void jacobi_rotate(double (&S)[3][3], double (&V)[3][3])
-{
-    const double apq = S[p][q];
-    if (apq == 0.0) return;
-    // (IEEE division and square root here: apq decays to subnormal values and theta overflows,
-    // outside the range of the refined hardware seeds)
-    const double theta = (S[q][q] - S[p][p]) / (2.0 * apq);
-    const double tt = ((theta >= 0.0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-    const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
-    constexpr int r = 3 - p - q;
-    const double app = S[p][p], aqq = S[q][q], arp = S[r][p], arq = S[r][q];
-    S[p][p] = app - tt * apq;
-    S[q][q] = aqq + tt * apq;
-    S[p][q] = S[q][p] = 0.0;
-    S[r][p] = S[p][r] = c * arp - s * arq;
-    S[r][q] = S[q][r] = s * arp + c * arq;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const double vkp = V[k][p], vkq = V[k][q];
-        V[k][p] = c * vkp - s * vkq;
-        V[k][q] = s * vkp + c * vkq;
-    }
-}
-
 // Nearest rotation to G (row-major 3x3) in the sense of the reference's
 // U diag(1, 1, det(U V^T)) V^T, and the largest singular value of G.  G^T G is diagonalised
 // by cyclic Jacobi sweeps; with singular pairs (sigma_k, v_k) sorted descending,
@@ -98,9 +71,9 @@ __device__ __forceinline__ void nearest_rotation(const double (&G)[9], double (&
 #pragma unroll
         for (int j = 0; j < 3; ++j) S[i][j] = G[i] * G[j] + G[3 + i] * G[3 + j] + G[6 + i] * G[6 + j];
     for (int sweep = 0; sweep < 8; ++sweep) {
-        jacobi_rotate<0, 1>(S, V);
-        jacobi_rotate<0, 2>(S, V);
-        jacobi_rotate<1, 2>(S, V);
+        jacobi_rotate<3, 0, 1>(S, V);
+        jacobi_rotate<3, 0, 2>(S, V);
+        jacobi_rotate<3, 1, 2>(S, V);
     }
     double lam[3] = {S[0][0], S[1][1], S[2][2]};
     auto swap_cols = [&](int a, int b) {
