@@ -57,7 +57,7 @@ def _np_dtype(uv, dtype):
 
 
 def solve_pnp_batch(uv, xyz, K, *, method="qeif", params=None, num_it=None, want_rpy=True,
-                    patterns=None, lm_lambda=1e-5, dtype=None):
+                    patterns=None, lm_lambda=1e-5, dtype=None, want_res=True):
     """Solve B independent PnP problems.
 
     uv       (B, N, 2) pixel coordinates, float32 or float64
@@ -74,6 +74,7 @@ def solve_pnp_batch(uv, xyz, K, *, method="qeif", params=None, num_it=None, want
     patterns optional (P, N, 3): QEIF against P shared patterns, keeping per problem the first
              with the smallest residual (the pattern loop of solve_pnp, :166-199); `xyz` is
              then ignored and the result gains "pattern_id"
+    want_res False leaves out res_norm (the DLT kernel then skips the residual of its last round)
     dtype    element type of the arrays handed to the kernels and of the results: float32
              (half the bytes) or float64 (the reference's dtype; agrees with it to float64
              round-off).  None follows `uv`: float64 if it is float64, float32 otherwise.
@@ -94,11 +95,11 @@ def solve_pnp_batch(uv, xyz, K, *, method="qeif", params=None, num_it=None, want
     extra = (num_it, float(lm_lambda))
     ft = _np_dtype(uv, dtype)
     if _is_torch(uv):
-        return _solve_torch(lib, uv, xyz, Kc, method, params, extra, want_rpy, patterns, ft)
-    return _solve_numpy(lib, uv, xyz, Kc, method, params, extra, want_rpy, patterns, ft)
+        return _solve_torch(lib, uv, xyz, Kc, method, params, extra, want_rpy, patterns, ft, want_res)
+    return _solve_numpy(lib, uv, xyz, Kc, method, params, extra, want_rpy, patterns, ft, want_res)
 
 
-def _solve_numpy(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, ft):
+def _solve_numpy(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, ft, want_res=True):
     uv = np.ascontiguousarray(uv, dtype=ft)
     src = patterns if patterns is not None else xyz
     src = np.ascontiguousarray(src, dtype=ft)
@@ -108,7 +109,9 @@ def _solve_numpy(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, f
         B, N, stride, n_pat = int(uv.shape[0]), int(uv.shape[1]), 0, int(src.shape[0])
     else:
         B, N, stride, n_pat = _shapes(uv.shape, src.shape)
-    out = dict(R=np.empty((B, 3, 3), ft), t=np.empty((B, 3), ft), res_norm=np.empty(B, ft))
+    out = dict(R=np.empty((B, 3, 3), ft), t=np.empty((B, 3), ft))
+    if want_res:
+        out["res_norm"] = np.empty(B, ft)
     rpy = np.empty((B, 3), ft) if want_rpy else None
     iters = np.empty(B, np.int32) if method == "qeif" else None
     pid = np.empty(B, np.int32) if patterns is not None else None
@@ -117,7 +120,7 @@ def _solve_numpy(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, f
         return None if a is None else a.ctypes.data
 
     _call(lib, method, ptr(uv), ptr(src), stride, n_pat, Kc, B, N, params, num_it, ptr(out["R"]),
-          ptr(out["t"]), ptr(out["res_norm"]), ptr(iters), ptr(rpy), ptr(pid), _lib.PTR_HOST, None,
+          ptr(out["t"]), ptr(out.get("res_norm")), ptr(iters), ptr(rpy), ptr(pid), _lib.PTR_HOST, None,
           patterns is not None, ft)
     out["t3"] = out["t"][:, 2].copy()
     if rpy is not None:
@@ -129,7 +132,7 @@ def _solve_numpy(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, f
     return out
 
 
-def _solve_torch(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, ft):
+def _solve_torch(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, ft, want_res=True):
     import torch
     tt = torch.float64 if ft == np.dtype(np.float64) else torch.float32
 
@@ -154,8 +157,9 @@ def _solve_torch(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, f
     dev = uv.device
     with torch.cuda.device(dev):
         out = dict(R=torch.empty((B, 3, 3), dtype=tt, device=dev),
-                   t=torch.empty((B, 3), dtype=tt, device=dev),
-                   res_norm=torch.empty(B, dtype=tt, device=dev))
+                   t=torch.empty((B, 3), dtype=tt, device=dev))
+        if want_res:
+            out["res_norm"] = torch.empty(B, dtype=tt, device=dev)
         rpy = torch.empty((B, 3), dtype=tt, device=dev) if want_rpy else None
         iters = torch.empty(B, dtype=torch.int32, device=dev) if method == "qeif" else None
         pid = torch.empty(B, dtype=torch.int32, device=dev) if patterns is not None else None
@@ -165,7 +169,7 @@ def _solve_torch(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, f
             return None if a is None else a.data_ptr()
 
         _call(lib, method, ptr(uv), ptr(src), stride, n_pat, Kc, B, N, params, num_it, ptr(out["R"]),
-              ptr(out["t"]), ptr(out["res_norm"]), ptr(iters), ptr(rpy), ptr(pid), _lib.PTR_DEVICE,
+              ptr(out["t"]), ptr(out.get("res_norm")), ptr(iters), ptr(rpy), ptr(pid), _lib.PTR_DEVICE,
               stream, patterns is not None, ft)
     out["t3"] = out["t"][:, 2]
     if rpy is not None:

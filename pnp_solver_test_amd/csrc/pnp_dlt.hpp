@@ -83,9 +83,10 @@ constexpr double kDltRankTol = 1e-13;
 // false if any round met a pivot at round-off, in which case its outputs are not to be used;
 // PINV = true solves every round through the pseudo-inverse of M and always returns true.  The
 // kernels run the first and repeat a problem with the second only when the first gives up.
+// want_res = false (uniform) skips the residual norm of the last round; res_out is then 30.
 template <int LPI, int NCT, bool PINV, typename PointFetch>
 __device__ __forceinline__ bool dlt_solve(const PointFetch &pts, int N, int lane_in_group,
-                                          int num_it, double (&R)[9], double (&t)[3],
+                                          int num_it, bool want_res, double (&R)[9], double (&t)[3],
                                           double &res_out)
 {
     double phi3[3] = {0.0, 0.0, 1.0};
@@ -164,6 +165,7 @@ __device__ __forceinline__ bool dlt_solve(const PointFetch &pts, int N, int lane
         const double f[8] = {rx[0], rx[1], rx[2], ry[0], ry[1], ry[2], rx[3], ry[3]};
         dlt_block_reconstruct(f, R, t, gam);
         if (it == num_it - 1) {
+            if (!want_res) break;
             // residual of the reconstructed pose against the system just solved
             const double fx[4] = {R[0] * gam, R[1] * gam, R[2] * gam, t[0] * gam};
             const double fy[4] = {R[3] * gam, R[4] * gam, R[5] * gam, t[1] * gam};

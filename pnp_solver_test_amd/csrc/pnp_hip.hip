@@ -390,7 +390,7 @@ int with_host_staging(hipStream_t s, int64_t B, int32_t N, size_t xyz_elems, con
     d.xyz = d_xyz;
     d.R = c.take<T>(nB * 9);
     d.t = c.take<T>(nB * 3);
-    d.res = c.take<T>(nB);
+    d.res = h.res ? c.take<T>(nB) : nullptr;
     d.rpy = h.rpy ? c.take<T>(nB * 3) : nullptr;
     d.iters = h.iters ? c.take<int32_t>(nB) : nullptr;
     d.pid = h.pid ? c.take<int32_t>(nB) : nullptr;

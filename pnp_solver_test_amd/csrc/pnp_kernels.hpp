@@ -398,15 +398,15 @@ __global__ __launch_bounds__(kSolveBlock<T>, PNP_DLT_WAVES) void dlt_kernel(
     bool sound;
     if constexpr (NCT > 0) {
         const RegPoints<NCT> rp(s.pts);
-        sound = dlt_solve<1, NCT, false>(rp, N, 0, num_it, R, t, res);
+        sound = dlt_solve<1, NCT, false>(rp, N, 0, num_it, res_out != nullptr, R, t, res);
     } else {
-        sound = dlt_solve<LPI, 0, false>(s.pts, N, s.lane_in_group, num_it, R, t, res);
+        sound = dlt_solve<LPI, 0, false>(s.pts, N, s.lane_in_group, num_it, res_out != nullptr, R, t, res);
     }
     // A problem whose normal equations were rank-deficient in some round (planar pattern, fewer
     // than four points) is solved again through the pseudo-inverse, from the points in LDS; the
     // registers of the first attempt are dead by now, so the rare path costs the common one none.
 #ifndef PNP_DLT_NO_PINV
-    if (!sound) dlt_solve<LPI, 0, true>(s.pts, N, s.lane_in_group, num_it, R, t, res);
+    if (!sound) dlt_solve<LPI, 0, true>(s.pts, N, s.lane_in_group, num_it, res_out != nullptr, R, t, res);
 #endif
 #ifdef PNP_DLT_DEBUG_MARK
     if (!sound) res = -1.0;
