@@ -498,6 +498,20 @@ def main():
             other["dlt_n6_b1m_float64_io"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4),
                                                   achieved_GBps=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4))
             del uv64, xyz64
+            # the host-pointer path: the same 1M problems handed over as NumPy arrays in pageable
+            # memory, copies over PCIe included (never the headline)
+            def host_call():
+                return pnp.solve_pnp_batch(uv_h, xyz_h, K, want_rpy=False)
+            host_call()
+            host_call()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                host_call()
+            hs = (time.perf_counter() - t0) / 5
+            other["qeif_n6_b1m_host_pointers_pcie_inclusive"] = dict(
+                solves_per_s=round(B / hs, 1), ms_per_call=round(hs * 1e3, 3),
+                pcie_GBps=round(B * (bytes_per_solve + 8) / hs / 1e9, 2),
+                what="NumPy arrays in, NumPy arrays out: chunks through page-locked buffers on 4 host threads and streams")
             line["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:   # last: the GPU idles (and clocks down) meanwhile
             line["cpu_baseline"] = cpu_baseline(uv_h, xyz_h, K)

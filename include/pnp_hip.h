@@ -28,6 +28,11 @@
  *   - Output pointers documented as optional may be NULL.
  *   - Thread safety: calls are independent as long as they do not share output buffers;
  *     host-pointer calls on one device serialise on that device's staging buffers.
+ *   - Host-pointer calls that move 16 MB or more are cut into chunks of about 8 MB which four
+ *     host threads (three started by the call, joined before it returns) carry through
+ *     page-locked buffers and streams of the library's own, so that the copy from the caller's
+ *     pageable arrays, the transfers in both directions and the kernels overlap.  Results are
+ *     those of one launch over the whole batch; work already queued on hip_stream is waited for.
  */
 #ifndef PNP_HIP_H
 #define PNP_HIP_H

@@ -10,6 +10,8 @@
 
 #include <atomic>
 #include <mutex>
+#include <thread>
+#include <vector>
 
 #include "pnp_hip.h"
 #include <algorithm>
@@ -62,11 +64,36 @@ constexpr int64_t kMomentMinBatch = 2048;
 
 // ---- per-device staging for host-pointer calls -------------------------------------------
 
+// Large host-pointer calls are cut into chunks that kPipeLanes host threads carry through the
+// device side by side, each with a stream, a page-locked buffer and a slice of device memory of
+// its own: while one lane copies a chunk from the caller's (pageable) arrays into its page-locked
+// buffer, another's chunk is on the bus, a third's is being solved and a fourth's results are on
+// their way back.  Measured on the pool's hosts: one thread copies pageable -> page-locked memory
+// at 23 GB/s, eight at 80 GB/s; page-locked memory crosses the bus at 57 GB/s in either direction,
+// both at once; pageable memory at 29 GB/s in and 18 GB/s out, one direction at a time.
+#ifndef PNP_PIPE_LANES
+#define PNP_PIPE_LANES 4
+#endif
+#ifndef PNP_PIPE_CHUNK_MB
+#define PNP_PIPE_CHUNK_MB 8
+#endif
+constexpr int kPipeLanes = PNP_PIPE_LANES;
+constexpr size_t kPipeChunkBytes = size_t(PNP_PIPE_CHUNK_MB) << 20;   // input bytes per chunk, about
+constexpr size_t kPipeMinBytes = size_t(16) << 20;    // calls moving less than this stay on one stream
+
+struct PipeLane {
+    hipStream_t stream = nullptr;
+    void *pinned = nullptr, *dev = nullptr;
+    size_t pinned_cap = 0, dev_cap = 0;
+};
+
 struct Staging {
     std::mutex mu;
     void *buf = nullptr;
     size_t cap = 0;
     void *pinned = nullptr;  // kSmallCall bytes of page-locked host memory, mirror of buf's first bytes
+    PipeLane lane[kPipeLanes];
+    hipEvent_t entry = nullptr;  // marks the caller's stream at the start of a pipelined call
 };
 
 // Host-pointer calls whose arrays fit this many bytes go through the pinned mirror: one copy in
@@ -262,15 +289,18 @@ int launch_qeif_moment(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_str
 template <typename T>
 int launch_qeif(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, int n_patterns,
                 const pnp::KinvRows &ki, int64_t B, int N, const pnp::QeifParams &p, T *R, T *t, T *res,
-                int32_t *iters, T *rpy, int32_t *pid)
+                int32_t *iters, T *rpy, int32_t *pid, int64_t plan_B = -1)
 {
     if (B == 0) return PNP_OK;
+    // plan_B: the size of the batch this launch is a chunk of; form and lanes per problem are
+    // chosen for that size, so that a chunked call computes exactly what one launch would
+    if (plan_B < B) plan_B = B;
     // the moment kernel addresses a workgroup's rows with 32-bit offsets: 256 rows of xyz_stride
-    if (use_moment_form(B, N, n_patterns) && xyz_stride <= (int64_t(1) << 22)) {
+    if (use_moment_form(plan_B, N, n_patterns) && xyz_stride <= (int64_t(1) << 22)) {
         if (pid) HIP_TRY(hipMemsetAsync(pid, 0, static_cast<size_t>(B) * sizeof(int32_t), s));
         return launch_qeif_moment<T>(s, uv, xyz, xyz_stride, ki, B, N, p, R, t, res, iters, rpy);
     }
-    const int lpi = choose_lpi(B, N, xyz_stride != 0, n_patterns, sizeof(T));
+    const int lpi = choose_lpi(plan_B, N, xyz_stride != 0, n_patterns, sizeof(T));
     const size_t lds = lds_bytes(lpi, N, xyz_stride != 0, n_patterns, sizeof(T));
     if (lds > 64 * 1024)
         return fail(PNP_E_ARG, "N = %d with %d pattern(s) needs %zu bytes of LDS per workgroup (max 65536)",
@@ -308,10 +338,11 @@ int launch_qeif(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, in
 
 template <typename T>
 int launch_dlt(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, const pnp::KinvRows &ki,
-               int64_t B, int N, int num_it, T *R, T *t, T *res, T *rpy)
+               int64_t B, int N, int num_it, T *R, T *t, T *res, T *rpy, int64_t plan_B = -1)
 {
     if (B == 0) return PNP_OK;
-    const int lpi = choose_lpi(B, N, xyz_stride != 0, 1, sizeof(T));
+    if (plan_B < B) plan_B = B;   // see launch_qeif
+    const int lpi = choose_lpi(plan_B, N, xyz_stride != 0, 1, sizeof(T));
     const size_t lds = lds_bytes(lpi, N, xyz_stride != 0, 1, sizeof(T));
     if (lds > 64 * 1024) return fail(PNP_E_ARG, "N = %d needs %zu bytes of LDS per workgroup (max 65536)", N, lds);
     constexpr int block = pnp::kSolveBlock<T>;
@@ -366,10 +397,135 @@ struct SolveIO {
     int32_t *iters, *pid;
 };
 
+// Grow-only resources of one pipeline lane of the current device; caller holds the staging lock.
+int lane_reserve(PipeLane &ln, size_t pinned_bytes, size_t dev_bytes)
+{
+    if (!ln.stream) HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+    if (pinned_bytes > ln.pinned_cap) {
+        if (ln.pinned) HIP_TRY(hipHostFree(ln.pinned));
+        ln.pinned = nullptr;
+        ln.pinned_cap = 0;
+        HIP_TRY(hipHostMalloc(&ln.pinned, pinned_bytes, hipHostMallocDefault));
+        ln.pinned_cap = pinned_bytes;
+    }
+    if (dev_bytes > ln.dev_cap) {
+        if (ln.dev) HIP_TRY(hipFree(ln.dev));
+        ln.dev = nullptr;
+        ln.dev_cap = 0;
+        HIP_TRY(hipMalloc(&ln.dev, dev_bytes));
+        ln.dev_cap = dev_bytes;
+    }
+    return PNP_OK;
+}
+
+// The chunked form of a host-pointer call (see kPipeLanes).  per_in / per_out: array elements per
+// problem that go in (uv, and xyz when every problem has its own) and come out.  The shared
+// pattern, if any, is already on the device at d_shared_xyz.  run(d, first, count, stream) solves
+// problems [first, first + count) from device pointers d that point at the chunk's own arrays.
+template <typename T, typename Run>
+int pipelined_host_call(Staging &st, int dev, hipStream_t s, int64_t B, int32_t N, bool own_xyz,
+                        const T *d_shared_xyz, const SolveIO<T> &h, Run run)
+{
+    const size_t in_per = (2 * static_cast<size_t>(N) + (own_xyz ? 3 * static_cast<size_t>(N) : 0)) * sizeof(T);
+    int64_t chunk = static_cast<int64_t>(kPipeChunkBytes / in_per);
+    chunk = std::max<int64_t>(1024, chunk & ~int64_t(255));
+    const int64_t nchunks = (B + chunk - 1) / chunk;
+    const int lanes = static_cast<int>(std::min<int64_t>(kPipeLanes, nchunks));
+    // one layout for the page-locked buffer and the device slice of a lane
+    struct Layout {
+        size_t uv, xyz, R, t, res, rpy, iters, pid, in_end, end;
+    } lay;
+    {
+        size_t off = 0;
+        auto take = [&off](size_t bytes) {   // 256-byte-aligned pieces, as Carver cuts them
+            const size_t at = off;
+            off += (bytes + 255) & ~static_cast<size_t>(255);
+            return at;
+        };
+        const size_t n = static_cast<size_t>(chunk);
+        lay.uv = take(n * 2 * N * sizeof(T));
+        lay.xyz = own_xyz ? take(n * 3 * N * sizeof(T)) : off;
+        lay.in_end = off;
+        lay.R = take(n * 9 * sizeof(T));
+        lay.t = take(n * 3 * sizeof(T));
+        lay.res = h.res ? take(n * sizeof(T)) : off;
+        lay.rpy = h.rpy ? take(n * 3 * sizeof(T)) : off;
+        lay.iters = h.iters ? take(n * sizeof(int32_t)) : off;
+        lay.pid = h.pid ? take(n * sizeof(int32_t)) : off;
+        lay.end = off;
+    }
+    for (int l = 0; l < lanes; ++l) {
+        const int rc = lane_reserve(st.lane[l], lay.end, lay.end);
+        if (rc) return rc;
+    }
+    // the lanes' streams start after whatever the caller's stream holds at this point
+    if (!st.entry) HIP_TRY(hipEventCreateWithFlags(&st.entry, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(st.entry, s));
+    for (int l = 0; l < lanes; ++l) HIP_TRY(hipStreamWaitEvent(st.lane[l].stream, st.entry, 0));
+
+    struct Outcome {
+        int rc = PNP_OK;
+        char msg[sizeof g_err] = "";
+    };
+    std::vector<Outcome> outcome(lanes);
+    auto work = [&](int l) {
+        Outcome &oc = outcome[l];
+        PipeLane &ln = st.lane[l];
+        auto body = [&]() -> int {
+            HIP_TRY(hipSetDevice(dev));
+            char *pin = static_cast<char *>(ln.pinned), *dv = static_cast<char *>(ln.dev);
+            for (int64_t k = l; k < nchunks; k += lanes) {
+                const int64_t first = k * chunk;
+                const size_t n = static_cast<size_t>(std::min<int64_t>(chunk, B - first));
+                std::memcpy(pin + lay.uv, h.uv + first * 2 * N, n * 2 * N * sizeof(T));
+                if (own_xyz) std::memcpy(pin + lay.xyz, h.xyz + first * 3 * N, n * 3 * N * sizeof(T));
+                HIP_TRY(hipMemcpyAsync(dv, pin, lay.in_end, hipMemcpyHostToDevice, ln.stream));
+                SolveIO<T> d;
+                d.uv = reinterpret_cast<const T *>(dv + lay.uv);
+                d.xyz = own_xyz ? reinterpret_cast<const T *>(dv + lay.xyz) : d_shared_xyz;
+                d.R = reinterpret_cast<T *>(dv + lay.R);
+                d.t = reinterpret_cast<T *>(dv + lay.t);
+                d.res = h.res ? reinterpret_cast<T *>(dv + lay.res) : nullptr;
+                d.rpy = h.rpy ? reinterpret_cast<T *>(dv + lay.rpy) : nullptr;
+                d.iters = h.iters ? reinterpret_cast<int32_t *>(dv + lay.iters) : nullptr;
+                d.pid = h.pid ? reinterpret_cast<int32_t *>(dv + lay.pid) : nullptr;
+                const int rc = run(d, static_cast<int64_t>(n), ln.stream);
+                if (rc) return rc;
+                HIP_TRY(hipMemcpyAsync(pin + lay.in_end, dv + lay.in_end, lay.end - lay.in_end, hipMemcpyDeviceToHost,
+                                       ln.stream));
+                HIP_TRY(hipStreamSynchronize(ln.stream));
+                std::memcpy(h.R + first * 9, pin + lay.R, n * 9 * sizeof(T));
+                std::memcpy(h.t + first * 3, pin + lay.t, n * 3 * sizeof(T));
+                if (h.res) std::memcpy(h.res + first, pin + lay.res, n * sizeof(T));
+                if (h.rpy) std::memcpy(h.rpy + first * 3, pin + lay.rpy, n * 3 * sizeof(T));
+                if (h.iters) std::memcpy(h.iters + first, pin + lay.iters, n * sizeof(int32_t));
+                if (h.pid) std::memcpy(h.pid + first, pin + lay.pid, n * sizeof(int32_t));
+            }
+            return PNP_OK;
+        };
+        oc.rc = body();
+        if (oc.rc) std::memcpy(oc.msg, g_err, sizeof oc.msg);   // g_err is this thread's own
+        (void)hipStreamSynchronize(ln.stream);                  // nothing of this lane stays in flight
+    };
+    std::vector<std::thread> helpers;
+    helpers.reserve(lanes - 1);
+    for (int l = 1; l < lanes; ++l) helpers.emplace_back(work, l);
+    work(0);
+    for (auto &th : helpers) th.join();
+    for (const Outcome &oc : outcome)
+        if (oc.rc) {
+            std::memcpy(g_err, oc.msg, sizeof g_err);
+            return oc.rc;
+        }
+    return PNP_OK;
+}
+
 // Copies the inputs of a host-pointer call to the device, runs `run` on device pointers and
 // copies the requested outputs back.  Synchronises the stream before returning.
+// run(d, count, stream) solves `count` problems from the device arrays d on `stream`.
 template <typename T, typename Run>
-int with_host_staging(hipStream_t s, int64_t B, int32_t N, size_t xyz_elems, const SolveIO<T> &h, Run run)
+int with_host_staging(hipStream_t s, int64_t B, int32_t N, size_t xyz_elems, bool own_xyz, const SolveIO<T> &h,
+                      Run run)
 {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
@@ -377,6 +533,17 @@ int with_host_staging(hipStream_t s, int64_t B, int32_t N, size_t xyz_elems, con
     Staging &st = g_staging[dev];
     std::lock_guard<std::mutex> lock(st.mu);
     const size_t nB = static_cast<size_t>(B);
+    if ((nB * 2 * N + (own_xyz ? xyz_elems : 0) + nB * 12) * sizeof(T) >= kPipeMinBytes) {
+        const T *d_shared = nullptr;
+        if (!own_xyz) {   // the shared pattern(s) go up once, ahead of the lanes
+            int rc = staging_reserve(st, xyz_elems * sizeof(T) + 256);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(st.buf, h.xyz, xyz_elems * sizeof(T), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            d_shared = static_cast<const T *>(st.buf);
+        }
+        return pipelined_host_call<T>(st, dev, s, B, N, own_xyz, d_shared, h, run);
+    }
     const size_t total = 256 * 10 + (nB * 2 * N + xyz_elems + nB * (9 + 3 + 1 + 3)) * sizeof(T) +
                          2 * nB * sizeof(int32_t);
     int rc = staging_reserve(st, total);
@@ -405,7 +572,7 @@ int with_host_staging(hipStream_t s, int64_t B, int32_t N, size_t xyz_elems, con
         std::memcpy(mirror(d_uv), h.uv, nB * 2 * N * sizeof(T));
         std::memcpy(mirror(d_xyz), h.xyz, xyz_elems * sizeof(T));
         HIP_TRY(hipMemcpyAsync(st.buf, m, in_bytes, hipMemcpyHostToDevice, s));
-        rc = run(d);
+        rc = run(d, B, s);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(m + in_bytes, static_cast<char *>(st.buf) + in_bytes, all_bytes - in_bytes,
                                hipMemcpyDeviceToHost, s));
@@ -421,7 +588,7 @@ int with_host_staging(hipStream_t s, int64_t B, int32_t N, size_t xyz_elems, con
 
     HIP_TRY(hipMemcpyAsync(d_uv, h.uv, nB * 2 * N * sizeof(T), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_xyz, h.xyz, xyz_elems * sizeof(T), hipMemcpyHostToDevice, s));
-    rc = run(d);
+    rc = run(d, B, s);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(h.R, d.R, nB * 9 * sizeof(T), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(h.t, d.t, nB * 3 * sizeof(T), hipMemcpyDeviceToHost, s));
@@ -473,9 +640,9 @@ int qeif_impl(const T *uv, const T *xyz, int64_t xyz_stride, int32_t n_patterns,
                               rpy_out, pid_out);
     const size_t xyz_elems = xyz_stride ? static_cast<size_t>(B) * 3 * N : static_cast<size_t>(n_patterns) * 3 * N;
     SolveIO<T> h{uv, xyz, R_out, t_out, res_out, rpy_out, iters_out, pid_out};
-    return with_host_staging<T>(s, B, N, xyz_elems, h, [&](const SolveIO<T> &d) {
-        return launch_qeif<T>(s, d.uv, d.xyz, xyz_stride, n_patterns, ki, B, N, q, d.R, d.t, d.res, d.iters, d.rpy,
-                              d.pid);
+    return with_host_staging<T>(s, B, N, xyz_elems, xyz_stride != 0, h, [&](const SolveIO<T> &d, int64_t count, hipStream_t on) {
+        return launch_qeif<T>(on, d.uv, d.xyz, xyz_stride, n_patterns, ki, count, N, q, d.R, d.t, d.res, d.iters,
+                              d.rpy, d.pid, B);
     });
 }
 
@@ -555,8 +722,8 @@ int dlt_impl(const T *uv, const T *xyz, int64_t xyz_stride, const double K[9], i
         return fail(PNP_E_ARG, "host-pointer calls take xyz_problem_stride 0 or 3*N only");
     const size_t xyz_elems = xyz_stride ? static_cast<size_t>(B) * 3 * N : static_cast<size_t>(3) * N;
     SolveIO<T> h{uv, xyz, R_out, t_out, res_out, rpy_out, nullptr, nullptr};
-    return with_host_staging<T>(s, B, N, xyz_elems, h, [&](const SolveIO<T> &d) {
-        return launch_dlt<T>(s, d.uv, d.xyz, xyz_stride, ki, B, N, num_it, d.R, d.t, d.res, d.rpy);
+    return with_host_staging<T>(s, B, N, xyz_elems, xyz_stride != 0, h, [&](const SolveIO<T> &d, int64_t count, hipStream_t on) {
+        return launch_dlt<T>(on, d.uv, d.xyz, xyz_stride, ki, count, N, num_it, d.R, d.t, d.res, d.rpy, B);
     });
 }
 
@@ -581,8 +748,8 @@ int lm12_impl(const T *uv, const T *xyz, int64_t xyz_stride, const double K[9], 
         return fail(PNP_E_ARG, "host-pointer calls take xyz_problem_stride 0 or 3*N only");
     const size_t xyz_elems = xyz_stride ? static_cast<size_t>(B) * 3 * N : static_cast<size_t>(3) * N;
     SolveIO<T> h{uv, xyz, R_out, t_out, res_out, rpy_out, nullptr, nullptr};
-    return with_host_staging<T>(s, B, N, xyz_elems, h, [&](const SolveIO<T> &d) {
-        return launch_lm12<T>(s, d.uv, d.xyz, xyz_stride, ki, B, N, lambda, num_it, d.R, d.t, d.res, d.rpy);
+    return with_host_staging<T>(s, B, N, xyz_elems, xyz_stride != 0, h, [&](const SolveIO<T> &d, int64_t count, hipStream_t on) {
+        return launch_lm12<T>(on, d.uv, d.xyz, xyz_stride, ki, count, N, lambda, num_it, d.R, d.t, d.res, d.rpy);
     });
 }
 

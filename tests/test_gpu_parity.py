@@ -392,6 +392,29 @@ def test_host_and_device_pointer_paths_agree(golden, torch_dev):
         assert host["R"].dtype == np.float32 and host["R"].shape == (777, 3, 3)
 
 
+def test_large_host_pointer_calls_agree_with_the_device_path(torch_dev):
+    """Host-pointer calls that move 16 MB or more are cut into chunks carried by several host
+    threads and streams; every output of every chunk must be what one device-pointer launch over
+    the whole batch gives, for sizes that leave a short last chunk and an idle lane."""
+    from pnp_solver_test_amd import synth
+    B = 300_007
+    uv, _ = synth.stress_batch(B, seed=11, pattern=synth.PATTERN6, K=K, is_quantized=True)
+    own = np.ascontiguousarray(np.broadcast_to(P6f, (B, 6, 3))) + np.float32(1e-4) * (np.arange(B, dtype=np.float32) % 7)[:, None, None]
+    pats = np.stack([P6f, po.pattern_array(po.PATTERN_HOLLY, po.LM6_KEYS).astype(np.float32)])
+    cases = [("qeif", dict(), own), ("qeif", dict(), P6f), ("dlt", dict(), own), ("lm12", dict(), own),
+             ("qeif", dict(patterns=pats), None), ("qeif", dict(want_rpy=False, want_res=False), own)]
+    for method, kw, xyz in cases:
+        host = pnp.solve_pnp_batch(uv, xyz, K, method=method, **kw)
+        dev = solve_dev(uv, xyz, torch_dev, method=method, **kw)
+        assert set(host) == set(dev)
+        for k in dev:
+            assert np.array_equal(dev[k], host[k], equal_nan=True), (method, sorted(kw), k)
+    # float64 arrays: twice the bytes per problem, other chunk boundaries
+    h64 = pnp.solve_pnp_batch(uv[:120_001].astype(np.float64), own[:120_001].astype(np.float64), K)
+    d64 = solve_dev64(uv[:120_001], own[:120_001], torch_dev)
+    assert all(np.array_equal(d64[k], h64[k]) for k in d64)
+
+
 @pytest.mark.parametrize("B", [1, 2, 63, 64, 255, 256, 257, 1000])
 def test_ragged_batches(golden, torch_dev, B):
     g, uv = stress_uv6(golden)
