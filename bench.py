@@ -298,10 +298,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    spinup_steps = spin_up(torch, step)
     for _ in range(args.warmup):
         out = step()
     barrier()
+    # The opening barrier of an N-rank run (a collective, on first use the communicator's set-up,
+    # and a host round trip) leaves the device idle long enough for its clock to drop, so the
+    # spin-up comes after it: it ends in a bare synchronize, and the clock starts right there.
+    spinup_steps = spin_up(torch, step)
     # One HIP event pair on the launch stream around the K launches: its span / K is the mean
     # launch duration, gaps between launches included.  (A pair around every launch puts two
     # markers between consecutive kernels and costs the loop 3 % of wall-clock, so only every
@@ -320,8 +323,10 @@ def main():
         else:
             out = step()
     ev_b.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    enqueue_s = time.perf_counter() - t0        # host time to queue the K launches
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0          # this rank's K steps, start to completion
+    barrier()                                   # every rank is done; the job's time is the slowest rank's
     kernel_ms = ev_a.elapsed_time(ev_b) / args.steps
     sampled = sorted(a.elapsed_time(b) for a, b in samples)
     if distributed:
@@ -361,6 +366,23 @@ def main():
         gather["to_rank_0_only"] = dict(solves_per_s=round(world * B * g_steps / float(gmax.item()), 1),
                                         ms_per_step=round(float(gmax.item()) / g_steps * 1e3, 4),
                                         what="solve + gather of R and t to rank 0 (RCCL)")
+        # and through the C ABI (pnp_gather_results on a communicator of the library's own)
+        comm = pnp.RcclComm.from_torch_group()
+        try:
+            for tag, dst in (("c_abi_all_gather", None), ("c_abi_to_rank_0_only", 0)):
+                pnp.gather_results({"R": out["R"], "t": out["t"]}, dst=dst, comm=comm)
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(g_steps):
+                    o = step()
+                    pnp.gather_results({"R": o["R"], "t": o["t"]}, dst=dst, comm=comm)
+                barrier()
+                gmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+                dist.all_reduce(gmax, op=dist.ReduceOp.MAX)
+                gather[tag] = dict(solves_per_s=round(world * B * g_steps / float(gmax.item()), 1),
+                                   ms_per_step=round(float(gmax.item()) / g_steps * 1e3, 4))
+        finally:
+            comm.close()
 
     if rank == 0:
         total = world * B * args.steps
@@ -390,6 +412,7 @@ def main():
             "spinup_steps": spinup_steps,
             "spinup_rule": ">= %.0f ms of untimed launches before every measurement" % SPINUP_MS,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

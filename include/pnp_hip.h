@@ -50,6 +50,7 @@ extern "C" {
 #define PNP_E_ARG (-1)     /* bad argument (NULL pointer, N out of range, ...) */
 #define PNP_E_HIP (-2)     /* a HIP runtime call failed                         */
 #define PNP_E_NODEVICE (-3)
+#define PNP_E_RCCL (-4)    /* RCCL could not be opened, or one of its calls failed */
 
 /* Tunables of the quaternion information-filter solver; the defaults are the constants
  * hard-coded in solve_pnp_QEIF_single_pattern (PNP_SOLVER_LIB.py:2791-2794, :2836,
@@ -216,6 +217,33 @@ int pnp_compare_batch_f64(const double *R_est, const double *t_est, const double
                           const double K[9], int64_t B, int32_t M, const double bound[4],
                           int32_t normalize, double *drpy_err, int32_t *pass_mask, double *lm_err,
                           int32_t *lm_key, int32_t ptr_kind, void *hip_stream);
+
+/* Optional exchange of result arrays between the ranks of a sharded solve (one process per GPU,
+ * every rank solving its own contiguous slice of the batch; the reference is single-process and
+ * has no counterpart).  The solve itself needs no communication; these four entry points are for
+ * a consumer that wants every rank's poses in one place.  They run on RCCL (xGMI between the GPUs
+ * of a node), which is opened at run time by the first of them that is called: the library loads
+ * without RCCL, and then these return PNP_E_RCCL.
+ *
+ * pnp_comm_unique_id  fills id_out[PNP_COMM_ID_BYTES] on ONE rank (ncclGetUniqueId); the caller
+ *                     hands the bytes to every other rank by means of its own (a file, MPI, a
+ *                     torch.distributed broadcast).
+ * pnp_comm_init       every rank, with its device current: joins the communicator of `world`
+ *                     ranks (ncclCommInitRank, collective) and returns it in *comm_out.
+ * pnp_comm_destroy    releases it.
+ * pnp_gather_results  send: this rank's bytes_per_rank bytes; recv: world * bytes_per_rank bytes,
+ *                     the ranks' arrays in rank order, on every rank (root < 0: ncclAllGather) or
+ *                     on rank `root` only (root >= 0: grouped ncclSend / ncclRecv, so that
+ *                     world - 1 slices arrive over world - 1 different links; recv may be NULL on
+ *                     the other ranks).  Device pointers; the same bytes_per_rank on every rank
+ *                     (pad shorter slices); enqueued on hip_stream, not synchronised.
+ *                     Collective: every rank of the communicator must call it. */
+#define PNP_COMM_ID_BYTES 128
+int pnp_comm_unique_id(void *id_out);
+int pnp_comm_init(const void *id, int32_t rank, int32_t world, void **comm_out);
+int pnp_comm_destroy(void *comm);
+int pnp_gather_results(const void *send, void *recv, int64_t bytes_per_rank, int32_t root,
+                       int32_t rank, int32_t world, void *comm, void *hip_stream);
 
 /* How many lanes of a wavefront cooperate on one problem: 1, 2, 4, 8, 16, 32 or 64
  * (64 = one wavefront per problem); 0 restores the automatic choice from (B, N).

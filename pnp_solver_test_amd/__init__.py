@@ -7,12 +7,12 @@ Python reaches through a C ABI with ctypes.  Importing this package loads that l
 raises ImportError if it has not been built: there is no CPU implementation to fall back to.
 """
 from . import _lib
-from .batch import (compare_batch, euler_deg_batch, gather_results, make_params, project_batch,
+from .batch import (RcclComm, compare_batch, euler_deg_batch, gather_results, make_params, project_batch,
                     shard_bounds, solve_pnp_batch)
 from .PNP_SOLVER_LIB import LM_KEY_LIST, PNP_SOLVER
 
 __all__ = ["PNP_SOLVER", "LM_KEY_LIST", "solve_pnp_batch", "euler_deg_batch", "make_params",
-           "shard_bounds", "gather_results", "project_batch", "compare_batch", "device_count", "version"]
+           "shard_bounds", "gather_results", "RcclComm", "project_batch", "compare_batch", "device_count", "version"]
 
 
 def device_count() -> int:

@@ -27,6 +27,7 @@ PTR_HOST = 0
 PTR_DEVICE = 1
 QEIF_FORM_AUTO, QEIF_FORM_POINTS, QEIF_FORM_MOMENTS = 0, 1, 2
 NOALLOC_SCRATCH_BYTES = 16 << 20      # PNP_NOALLOC_SCRATCH_BYTES
+COMM_ID_BYTES = 128                   # PNP_COMM_ID_BYTES
 
 #: every symbol include/pnp_hip.h declares
 EXPORTS = (
@@ -36,6 +37,7 @@ EXPORTS = (
     "pnp_qeif_multi_batch_f64", "pnp_project_batch_f64", "pnp_compare_batch_f32", "pnp_compare_batch_f64",
     "pnp_set_lanes_per_problem", "pnp_get_lanes_per_problem", "pnp_set_qeif_form", "pnp_get_qeif_form",
     "pnp_max_points", "pnp_qeif_batch_noalloc_f32",
+    "pnp_comm_unique_id", "pnp_comm_init", "pnp_comm_destroy", "pnp_gather_results",
     "pnp_last_error", "pnp_version",
 )
 
@@ -90,6 +92,14 @@ def load():
             fn.restype = ctypes.c_int
     lib.pnp_qeif_batch_noalloc_f32.argtypes = [vp, vp, i64, dp, i64, i32, pp, vp, vp, vp, vp, vp, vp]
     lib.pnp_qeif_batch_noalloc_f32.restype = ctypes.c_int
+    lib.pnp_comm_unique_id.argtypes = [vp]
+    lib.pnp_comm_unique_id.restype = ctypes.c_int
+    lib.pnp_comm_init.argtypes = [vp, i32, i32, ctypes.POINTER(vp)]
+    lib.pnp_comm_init.restype = ctypes.c_int
+    lib.pnp_comm_destroy.argtypes = [vp]
+    lib.pnp_comm_destroy.restype = ctypes.c_int
+    lib.pnp_gather_results.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
+    lib.pnp_gather_results.restype = ctypes.c_int
     lib.pnp_project_batch_f64.argtypes = [vp, vp, vp, i64, dp, i64, i32, ctypes.c_double, vp, i32, i32, vp]
     lib.pnp_project_batch_f64.restype = ctypes.c_int
     lib.pnp_set_lanes_per_problem.argtypes = [i32]

@@ -237,14 +237,90 @@ def shard_bounds(total: int, rank: int, world_size: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_results(local: dict, group=None, dst=None):
+class RcclComm:
+    """A communicator of libpnp_hip.so's own over RCCL (pnp_comm_init), for the optional result
+    exchange through the C ABI, pnp_gather_results: no torch.distributed on the data path.  One
+    per process; the process's HIP device must be current when it is created and used."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes):
+        lib = _lib.load()
+        if len(unique_id) != _lib.COMM_ID_BYTES:
+            raise ValueError("unique_id must be %d bytes" % _lib.COMM_ID_BYTES)
+        self.rank, self.world = int(rank), int(world)
+        self._comm = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(unique_id, _lib.COMM_ID_BYTES)
+        _lib.check(lib.pnp_comm_init(buf, self.rank, self.world, ctypes.byref(self._comm)))
+
+    @staticmethod
+    def unique_id() -> bytes:
+        """On ONE rank; hand the bytes to the others (file, MPI, torch.distributed broadcast)."""
+        buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+        _lib.check(_lib.load().pnp_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_torch_group(cls, group=None):
+        """Rank 0 of a torch.distributed group draws the id and broadcasts it; every rank joins."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(rank, world, box[0])
+
+    def gather(self, val, dst=None):
+        """val: a contiguous torch tensor on this process's HIP device, same shape on every rank.
+        Returns the ranks' tensors concatenated along dim 0, on every rank (dst None) or on rank
+        dst only (None elsewhere).  Enqueued on torch's current stream."""
+        import torch
+        if not val.is_cuda:
+            raise ValueError("RcclComm.gather takes tensors on a HIP device")
+        val = val.contiguous()
+        receives = dst is None or dst == self.rank
+        out = torch.empty((self.world * val.shape[0],) + tuple(val.shape[1:]), dtype=val.dtype,
+                          device=val.device) if receives else None
+        with torch.cuda.device(val.device):
+            _lib.check(_lib.load().pnp_gather_results(
+                val.data_ptr(), out.data_ptr() if receives else None, val.numel() * val.element_size(),
+                -1 if dst is None else int(dst), self.rank, self.world, self._comm,
+                torch.cuda.current_stream(val.device).cuda_stream))
+        return out
+
+    def close(self):
+        if self._comm:
+            _lib.check(_lib.load().pnp_comm_destroy(self._comm))
+            self._comm = ctypes.c_void_p()
+
+
+def _gather_through_comm(local: dict, comm: RcclComm, dst):
+    import torch
+    first = next(iter(local.values()))
+    counts = comm.gather(torch.tensor([first.shape[0]], dtype=torch.int64, device=first.device)).tolist()
+    n_max = max(counts)
+    out = {}
+    for key, val in local.items():
+        val = val.contiguous()
+        if val.shape[0] < n_max:
+            pad = torch.zeros((n_max - val.shape[0],) + tuple(val.shape[1:]), dtype=val.dtype, device=val.device)
+            val = torch.cat([val, pad], dim=0)
+        buf = comm.gather(val, dst)
+        if buf is None:
+            continue
+        out[key] = buf if min(counts) == n_max else torch.cat(
+            [buf[r * n_max:r * n_max + counts[r]] for r in range(comm.world)], dim=0)
+    return out if (dst is None or dst == comm.rank) else None
+
+
+def gather_results(local: dict, group=None, dst=None, comm=None):
     """Optional collective after a sharded solve: every rank's result arrays (torch tensors) in
     rank order, on every rank (all-gather, the default) or on rank `dst` only (gather; the other
     ranks get None).  Gathering to one rank moves world-1 slices over world-1 different xGMI
     links at once instead of world-1 slices into every rank.  Slices may differ in length
     (shard_bounds hands out sizes that differ by one): shorter ones are padded for the collective
     and trimmed afterwards.  Uses torch.distributed, i.e. RCCL over xGMI for HIP tensors and gloo
-    for CPU tensors."""
+    for CPU tensors - or, with comm= an RcclComm, the C ABI's pnp_gather_results (device tensors
+    only, nothing of torch.distributed involved)."""
+    if comm is not None:
+        return _gather_through_comm(local, comm, dst)
     import torch
     import torch.distributed as dist
 

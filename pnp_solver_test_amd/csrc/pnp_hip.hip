@@ -914,6 +914,8 @@ int compare_impl(const T *R_est, const T *t_est, const T *uv_obs, const double *
     return PNP_OK;
 }
 
+#include "pnp_gather.hpp"
+
 }  // namespace
 
 // ================================================================================================
@@ -1078,6 +1080,23 @@ int pnp_compare_batch_f64(const double *R_est, const double *t_est, const double
 {
     return compare_impl<double>(R_est, t_est, uv_obs, rpy_gt_deg, distance_gt_cm, xyz, K, B, M, bound, normalize,
                                 drpy_err, pass_mask, lm_err, lm_key, ptr_kind, hip_stream);
+}
+
+// ---- optional exchange between ranks ---------------------------------------------------------------
+
+int pnp_comm_unique_id(void *id_out) { return comm_unique_id_impl(id_out); }
+
+int pnp_comm_init(const void *id, int32_t rank, int32_t world, void **comm_out)
+{
+    return comm_init_impl(id, rank, world, comm_out);
+}
+
+int pnp_comm_destroy(void *comm) { return comm_destroy_impl(comm); }
+
+int pnp_gather_results(const void *send, void *recv, int64_t bytes_per_rank, int32_t root, int32_t rank, int32_t world,
+                       void *comm, void *hip_stream)
+{
+    return gather_impl(send, recv, bytes_per_rank, root, rank, world, comm, static_cast<hipStream_t>(hip_stream));
 }
 
 // ---- tuning and introspection -----------------------------------------------------------------------
