@@ -405,12 +405,7 @@ __global__ __launch_bounds__(kSolveBlock<T>, PNP_DLT_WAVES) void dlt_kernel(
     // A problem whose normal equations were rank-deficient in some round (planar pattern, fewer
     // than four points) is solved again through the pseudo-inverse, from the points in LDS; the
     // registers of the first attempt are dead by now, so the rare path costs the common one none.
-#ifndef PNP_DLT_NO_PINV
     if (!sound) dlt_solve<LPI, 0, true>(s.pts, N, s.lane_in_group, num_it, res_out != nullptr, R, t, res);
-#endif
-#ifdef PNP_DLT_DEBUG_MARK
-    if (!sound) res = -1.0;
-#endif
     if (s.store) {
         store_pose(s.problem, R, t, R_out, t_out);
         if (res_out) res_out[s.problem] = static_cast<T>(res);

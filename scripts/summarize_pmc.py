@@ -68,10 +68,22 @@ for label, kern, B, N, own in LAUNCHES:
     s["hbm_bytes_per_launch"] = s["fetch_bytes_2x"] + s["write_bytes"]
     s["fetch_2x_over_input"] = round(s["fetch_bytes_2x"] / in_bytes, 4)
     if "moment" in kern:
-        # 4-byte-per-lane loads in 64/128-byte runs: the doubling rule is calibrated for 16 B/lane
-        # streaming reads only, so the true read traffic lies between the raw and the doubled figure
-        s["fetch_calibration"] = "uncalibrated access width: between FETCH_SIZE (%.3f x input) and 2 x FETCH_SIZE (%.3f x input)" % (
-            s["fetch_bytes_2x"] / 2 / in_bytes, s["fetch_bytes_2x"] / in_bytes)
+        # The moment kernel reads 4 bytes per lane in runs of 2C pixel floats / 3C pattern floats per
+        # problem row; FETCH_SIZE counts such reads neither at 1/2 (the 16-bytes-per-lane rule) nor
+        # at 1.  scripts/probes/fetch_calibration.hip reads a known byte count once in each of
+        # these shapes (N = 68 rows): FETCH_SIZE bytes / true bytes = 0.7696 for 64-byte runs
+        # (pixels, C = 8), 0.9288 for 128-byte runs (pixels, C = 16), 1.1093 for 96-byte runs
+        # (pattern, C = 8).  Divided out, what is left is the kernel's re-read ratio.
+        C = 8 if own else 16
+        uv_b, xyz_b = B * 8 * N, (B * 12 * N if own else 0)
+        counted_if_read_once = (0.7696 if C == 8 else 0.9288) * uv_b + 1.1093 * xyz_b
+        ratio = s["FETCH_SIZE"] * 1024 / counted_if_read_once
+        s["fetch_calibration"] = ("FETCH_SIZE calibrated on this access shape (scripts/probes/fetch_calibration.hip): "
+                                  "a single read of the inputs would count %.0f bytes" % counted_if_read_once)
+        s["read_bytes_over_input"] = round(ratio, 4)
+        s["fetch_bytes_calibrated"] = ratio * in_bytes
+        s["hbm_bytes_per_launch"] = s["fetch_bytes_calibrated"] + s["write_bytes"]
+        del s["fetch_bytes_2x"], s["fetch_2x_over_input"]
     if "SQ_ACTIVE_INST_VALU" in s and "GRBM_GUI_ACTIVE" in s:
         # SQ_* activity counters tick in quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs
         s["valu_busy_frac"] = round(4 * s["SQ_ACTIVE_INST_VALU"] / 1024 / (s["GRBM_GUI_ACTIVE"] / 8), 4)
@@ -84,4 +96,4 @@ traffic["qeif_n6_b1m_bytes_per_launch"] = traffic.get("qeif_n6_b1m_per_problem_x
 traffic["source"] = "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % tag
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1, sort_keys=True)
 for label, s in summary.items():
-    print(label, {k: s[k] for k in ("hbm_bytes_per_launch", "fetch_2x_over_input", "valu_busy_frac", "valu_insts_per_wave") if k in s})
+    print(label, {k: s[k] for k in ("hbm_bytes_per_launch", "fetch_2x_over_input", "read_bytes_over_input", "valu_busy_frac", "valu_insts_per_wave") if k in s})
