@@ -467,7 +467,7 @@ int pipelined_host_call(Staging &st, int dev, hipStream_t s, int64_t B, int32_t 
         int rc = PNP_OK;
         char msg[sizeof g_err] = "";
     };
-    std::vector<Outcome> outcome(lanes);
+    Outcome outcome[kPipeLanes];
     auto work = [&](int l) {
         Outcome &oc = outcome[l];
         PipeLane &ln = st.lane[l];
@@ -507,15 +507,22 @@ int pipelined_host_call(Staging &st, int dev, hipStream_t s, int64_t B, int32_t 
         if (oc.rc) std::memcpy(oc.msg, g_err, sizeof oc.msg);   // g_err is this thread's own
         (void)hipStreamSynchronize(ln.stream);                  // nothing of this lane stays in flight
     };
+    // lanes 1.. on helper threads; a lane whose thread cannot be started is worked off here,
+    // after lane 0 (nothing may be thrown through the C ABI)
     std::vector<std::thread> helpers;
-    helpers.reserve(lanes - 1);
-    for (int l = 1; l < lanes; ++l) helpers.emplace_back(work, l);
+    int started = 1;
+    try {
+        helpers.reserve(lanes - 1);
+        for (; started < lanes; ++started) helpers.emplace_back(work, started);
+    } catch (...) {
+    }
     work(0);
+    for (int l = started; l < lanes; ++l) work(l);
     for (auto &th : helpers) th.join();
-    for (const Outcome &oc : outcome)
-        if (oc.rc) {
-            std::memcpy(g_err, oc.msg, sizeof g_err);
-            return oc.rc;
+    for (int l = 0; l < lanes; ++l)
+        if (outcome[l].rc) {
+            std::memcpy(g_err, outcome[l].msg, sizeof g_err);
+            return outcome[l].rc;
         }
     return PNP_OK;
 }
