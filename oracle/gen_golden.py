@@ -95,7 +95,7 @@ def main():
     ap.add_argument('--ref', default='/root/reference/scripts')
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
     ap.add_argument('--n-stress', type=int, default=10000)
-    ap.add_argument('--only', default='', help='comma-separated section numbers (1-13); default all')
+    ap.add_argument('--only', default='', help='comma-separated section numbers (1-14); default all')
     args = ap.parse_args()
     out_dir = os.path.abspath(args.out)
     os.makedirs(out_dir, exist_ok=True)
@@ -552,6 +552,54 @@ def main():
                     res.append((np.full((3, 3), nan), np.full((3, 1), nan), nan, nan, nan, nan, nan))
         save('dlt_planar.npz', seed=np.int64(48), kinds=np.array(kinds), kind_id=kind_id, uv=uv, xyz=xyz,
              keys=np.array(LM6), raised=raised, **pack(res))
+
+    # ---- 14. QEIF on all 15 landmarks of the golden face, and on a second 68-point pattern ---------
+    if want(14):
+        import contextlib
+        import io
+        sink = io.StringIO()
+        c15 = IterCounter(est, 'QEKF_get_hx_H')
+        n = 1024
+        rng = np.random.default_rng(49)
+        uv = np.zeros((n, 15, 2), dtype=np.float32)
+        iters = np.zeros(n, dtype=np.int32)
+        res = []
+        for i in range(n):
+            roll, pitch, yaw, t = draw_stress_pose(rng)
+            R = gt.get_rotation_matrix_from_Euler(roll, yaw, pitch, is_degree=True)
+            img = gt.perspective_projection_golden_landmarks(R, t, is_quantized=(i % 2 == 0))
+            uv[i] = dict_to_uv(img, keys15).astype(np.float32)
+            c15.n = 0
+            res.append(est.solve_pnp_QEIF_single_pattern(uv_to_dict(uv[i].astype(np.float64), keys15),
+                                                         est.np_point_3d_pretransfer_dict_list[0], LM_key_list=None))
+            iters[i] = c15.n
+        save('qeif_n15.npz', seed=np.int64(49), keys=np.array(keys15), uv=uv, iters=iters,
+             quantized=(np.arange(n) % 2 == 0), **pack(res))
+
+        n = 384
+        P68 = np.random.default_rng(1).uniform([-0.09, -0.06, -0.05], [0.09, 0.10, 0.03], (68, 3))
+        P68 = np.round(P68 * 4096.0) / 4096.0           # on a 2^-12 m grid: exact in float32
+        keys68 = ['q%02d' % i for i in range(68)]
+        pat68 = {k: P68[i].tolist() for i, k in enumerate(keys68)}
+        with contextlib.redirect_stdout(sink):
+            gt68 = PNPS.PNP_SOLVER(K, [pat68], verbose=False)
+            est68 = PNPS.PNP_SOLVER(K, [pat68], verbose=False)
+        c68 = IterCounter(est68, 'QEKF_get_hx_H')
+        rng = np.random.default_rng(50)
+        uv = np.zeros((n, 68, 2), dtype=np.float32)
+        iters = np.zeros(n, dtype=np.int32)
+        res = []
+        for i in range(n):
+            roll, pitch, yaw, t = draw_stress_pose(rng)
+            R = gt68.get_rotation_matrix_from_Euler(roll, yaw, pitch, is_degree=True)
+            img = gt68.perspective_projection_golden_landmarks(R, t, is_quantized=True, quantize_q=0.25)
+            uv[i] = dict_to_uv(img, keys68).astype(np.float32)
+            c68.n = 0
+            res.append(est68.solve_pnp_QEIF_single_pattern(
+                uv_to_dict(uv[i].astype(np.float64), keys68),
+                est68.np_point_3d_pretransfer_dict_list[0], LM_key_list=None))
+            iters[i] = c68.n
+        save('qeif_n68_b.npz', seed=np.int64(50), xyz=P68, uv=uv, iters=iters, **pack(res))
 
     print('done in %.0f s; numpy %s' % (time.time() - t_start, np.__version__))
 

@@ -26,6 +26,9 @@ constexpr int kMomentBlock = 1024 / static_cast<int>(sizeof(T));
 #ifndef PNP_QEIF_WAVES
 #define PNP_QEIF_WAVES 2  // minimum resident waves per SIMD the QEIF kernels are compiled for
 #endif
+#ifndef PNP_MOMENT_WAVES
+#define PNP_MOMENT_WAVES 2  // the same for the moment-form QEIF kernel
+#endif
 #ifndef PNP_DLT_WAVES
 #define PNP_DLT_WAVES 3   // the same for the DLT kernels
 #endif

@@ -225,7 +225,7 @@ constexpr int kMomentChunkShared = 64 / static_cast<int>(sizeof(T));
 // Dynamic LDS: SHARED ? 2 C (BLOCK + 1) elements, rounded up to 8 bytes, + 9 N doubles
 //                     : 5 C (BLOCK + 1) elements.
 template <typename T, int C, bool SHARED>
-__global__ __launch_bounds__(kMomentBlock<T>, PNP_QEIF_WAVES) void qeif_moment_kernel(
+__global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment_kernel(
     const T *__restrict__ uv, const T *__restrict__ xyz, int64_t xyz_stride, KinvRows ki, int64_t B, int N,
     QeifParams p, T *__restrict__ R_out, T *__restrict__ t_out, T *__restrict__ res_out,
     int32_t *__restrict__ iters_out, T *__restrict__ rpy_out)

@@ -1084,6 +1084,40 @@ def test_moment_form_n68_against_reference(golden, torch_dev, moment_form):
     assert np.array_equal(host["R"], f32["R"]) and np.array_equal(host["rpy_deg"], f32["rpy_deg"])
 
 
+@pytest.mark.parametrize("form", ["points", "moments"])
+def test_qeif_n15_and_a_second_68_point_pattern(golden, torch_dev, form):
+    """Two more reference runs: all 15 landmarks of the golden face (every other problem with
+    unquantised pixels) and a 68-point pattern whose coordinates are exact in float32 (so the
+    float32 flavour sees the reference's own inputs), each through both forms of the kernel."""
+    lib = _lib.load()
+    g, b = golden("qeif_n15"), golden("qeif_n68_b")
+    lib.pnp_set_qeif_form(_lib.QEIF_FORM_POINTS if form == "points" else _lib.QEIF_FORM_MOMENTS)
+    try:
+        o15 = solve_dev64(g["uv"], P15, torch_dev)
+        f15 = solve_dev(g["uv"], P15.astype(np.float32), torch_dev)
+        o68 = solve_dev64(b["uv"], b["xyz"], torch_dev)
+        f68 = solve_dev(b["uv"], b["xyz"], torch_dev)
+        own = solve_dev(b["uv"], np.broadcast_to(b["xyz"], (len(b["uv"]), 68, 3)), torch_dev)
+    finally:
+        lib.pnp_set_qeif_form(_lib.QEIF_FORM_AUTO)
+    q = g["quantized"]
+    assert np.array_equal(o15["iters"][q], g["iters"][q])
+    same = o15["iters"] == g["iters"]
+    assert same.mean() >= 0.97           # exact pixels: the stopping rule sits on the rounding floor
+    assert np.abs(o15["R"] - g["R"])[same].max() <= DR_F64 and rel_t(o15["t"][same], g["t"][same]).max() <= RELT_F64
+    same = f15["iters"] == g["iters"]
+    assert same[q].mean() >= 0.999 and same.mean() >= 0.97
+    assert rot_angle(f15["R"], g["R"])[same].max() <= ANG_TOL and rel_t(f15["t"][same], g["t"][same]).max() <= RELT_TOL
+    # the 68-point pattern: identical inputs in both flavours, so the reference itself is the bar
+    assert np.array_equal(o68["iters"], b["iters"])
+    assert np.abs(o68["R"] - b["R"]).max() <= DR_F64 and rel_t(o68["t"], b["t"]).max() <= RELT_F64
+    assert np.abs(o68["res_norm"] - b["res_norm"]).max() <= 1e-9
+    for f in (f68, own):
+        assert np.array_equal(f["iters"], b["iters"])
+        assert_tight(f, {k: b[k] for k in ("R", "t", "res_norm")})
+    assert np.array_equal(f68["R"], own["R"]) or np.abs(f68["R"] - own["R"]).max() <= 2e-7
+
+
 @pytest.mark.parametrize("r_quat,r_delta", [(1e-4, 1e-5), (1e-7, 1e-7), (10.0, 1.0), (1e3, 1e-6)])
 def test_moment_form_process_noise_range(golden, torch_dev, moment_form, r_quat, r_delta):
     """The predict step's difference form (see test_qeif_process_noise_range) in the moment

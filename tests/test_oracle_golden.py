@@ -90,6 +90,29 @@ def test_qeif_n68(golden):
     assert np.array_equal(q["R"], g["R"][3])
 
 
+def test_qeif_n15_and_a_second_68_point_pattern(golden):
+    """All 15 landmarks of the golden face (half the problems with unquantised pixels), and a
+    68-point pattern on a 2^-12 m grid with quarter-pixel quantisation, as the reference solved
+    them."""
+    g = golden("qeif_n15")
+    r = c_oracle.qeif_batch(g["uv"].astype(np.float64), P15, K)
+    q = g["quantized"]
+    assert np.array_equal(r["iters"][q], g["iters"][q])
+    same = r["iters"] == g["iters"]
+    assert same.mean() >= 0.97          # exact pixels stop at the rounding floor: see the N = 6 case
+    assert np.abs(r["R"] - g["R"])[same].max() < 1e-10 and np.abs(r["t"] - g["t"])[same].max() < 1e-10
+    assert np.abs(r["res_norm"] - g["res_norm"])[same].max() < 1e-11
+    for i in (0, 1, 500):
+        o = po.qeif_solve(g["uv"][i].astype(np.float64), P15, K)
+        assert np.array_equal(o["R"], g["R"][i]) and o["iters"] == g["iters"][i]
+    b = golden("qeif_n68_b")
+    assert np.array_equal(b["xyz"], b["xyz"].astype(np.float32))
+    r = c_oracle.qeif_batch(b["uv"].astype(np.float64), b["xyz"], K)
+    assert np.array_equal(r["iters"], b["iters"])
+    assert np.abs(r["R"] - b["R"]).max() < 1e-10 and np.abs(r["t"] - b["t"]).max() < 1e-10
+    assert np.abs(r["rpy"] - rpy_of(b)).max() < 1e-8
+
+
 def test_qeif_per_problem_patterns_equal_shared(golden):
     g = golden("stress_qeif_n6")
     uv = g["uv15"][:64, lm6_indices(g), :].astype(np.float64)
