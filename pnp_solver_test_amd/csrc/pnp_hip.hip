@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -246,6 +247,10 @@ pnp::QeifParams to_device_params(const pnp_qeif_params *p)
 
 // ---- launchers (device pointers only; T = element type of the problem arrays) ----------------
 
+// Experiment switch (environment PNP_MOMENT_PLAIN=1): per-problem patterns through the equal-chunk
+// moment kernel instead of the line-cut one.
+std::atomic<bool> g_moment_plain{getenv("PNP_MOMENT_PLAIN") != nullptr && getenv("PNP_MOMENT_PLAIN")[0] == '1'};
+
 // True when a QEIF launch should run in moment form.
 bool use_moment_form(int64_t B, int N, int n_patterns)
 {
@@ -278,9 +283,33 @@ int launch_qeif_moment(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_str
             hipLaunchKernelGGL((pnp::qeif_moment_kernel<T, c_own, true>), grid, dim3(block), lds_short, s, uv, xyz,
                                xyz_stride, ki, B, N, p, R, t, res, iters, rpy);
     } else {
-        const size_t lds = 5 * c_own * row * sizeof(T);
-        hipLaunchKernelGGL((pnp::qeif_moment_kernel<T, c_own, false>), grid, dim3(block), lds, s, uv, xyz,
-                           xyz_stride, ki, B, N, p, R, t, res, iters, rpy);
+        // chunks cut at the cache lines: all of a CU's LDS between two workgroups, which a kernel
+        // has to be allowed once per device
+        constexpr size_t lines_lds = static_cast<size_t>(5) * pnp::kMomentChunkLine<T> * block * sizeof(T);
+        static std::atomic<uint64_t> allowed{0}, refused{0};
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        const uint64_t bit = uint64_t(1) << (dev & 63);
+        if (!((allowed.load() | refused.load()) & bit)) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pnp::qeif_moment_lines_kernel<T>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     static_cast<int>(lines_lds));
+            if (e != hipSuccess) (void)hipGetLastError();
+            (e == hipSuccess ? allowed : refused).fetch_or(bit);
+        }
+        const hipError_t lines_ready = (allowed.load() & bit) ? hipSuccess : hipErrorInvalidValue;
+        // its loads address a workgroup's rows through 32-bit byte offsets
+        const bool offsets_fit = static_cast<uint64_t>(block) * static_cast<uint64_t>(xyz_stride) * sizeof(T) < (uint64_t(1) << 31);
+        // measured on 256k-512k problems: ahead from about 24 float32 (12 float64) points per problem
+        const bool long_rows = static_cast<size_t>(N) * sizeof(T) >= 96;
+        if (lines_ready == hipSuccess && offsets_fit && long_rows && !g_moment_plain.load()) {
+            hipLaunchKernelGGL((pnp::qeif_moment_lines_kernel<T>), grid, dim3(block), lines_lds, s, uv, xyz, xyz_stride, ki,
+                               B, N, p, R, t, res, iters, rpy);
+        } else {
+            const size_t lds = 5 * c_own * row * sizeof(T);
+            hipLaunchKernelGGL((pnp::qeif_moment_kernel<T, c_own, false>), grid, dim3(block), lds, s, uv, xyz,
+                               xyz_stride, ki, B, N, p, R, t, res, iters, rpy);
+        }
     }
     HIP_TRY(hipGetLastError());
     return PNP_OK;

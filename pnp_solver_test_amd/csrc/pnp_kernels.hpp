@@ -208,6 +208,53 @@ __global__ __launch_bounds__(kSolveBlock<T>, PNP_QEIF_WAVES) void qeif_kernel(
     }
 }
 
+// The iterations of the moment form for one problem (one lane) from its accumulated sums, and the
+// stores of its results.  The residual of the stopping rule falls back to the points themselves
+// (exact_ss) where the moment expression would be round-off.
+template <typename T>
+__device__ __forceinline__ void moment_iterations(Moments &M, const T *__restrict__ uv, const T *__restrict__ xyz,
+                                                  int64_t xyz_stride, const KinvRows &ki, int64_t problem, int N,
+                                                  const QeifParams &p, T *__restrict__ R_out, T *__restrict__ t_out,
+                                                  T *__restrict__ res_out, int32_t *__restrict__ iters_out,
+                                                  T *__restrict__ rpy_out)
+{
+    const T *my_uv = uv + problem * 2 * N;
+    const T *my_xyz = xyz + problem * xyz_stride;
+    auto exact_ss = [&](const double (&x)[6]) {
+        double phi[9], gamma, ss = 0.0;
+        gamma_matrix(x, phi, gamma);
+        for (int i = 0; i < N; ++i) {
+            const double u = static_cast<double>(my_uv[2 * i]), v = static_cast<double>(my_uv[2 * i + 1]);
+            const double X = static_cast<double>(my_xyz[3 * i]), Y = static_cast<double>(my_xyz[3 * i + 1]);
+            const double Z = static_cast<double>(my_xyz[3 * i + 2]);
+            const double bx = __builtin_fma(ki.a00, u, __builtin_fma(ki.a01, v, ki.a02));
+            const double by = __builtin_fma(ki.a10, u, __builtin_fma(ki.a11, v, ki.a12));
+            const double p1 = __builtin_fma(X, phi[0], __builtin_fma(Y, phi[1], Z * phi[2]));
+            const double p2 = __builtin_fma(X, phi[3], __builtin_fma(Y, phi[4], Z * phi[5]));
+            const double p3 = __builtin_fma(X, phi[6], __builtin_fma(Y, phi[7], Z * phi[8]));
+            const double rx = (bx - x[4]) - __builtin_fma(-bx, p3, p1);
+            const double ry = (by - x[5]) - __builtin_fma(-by, p3, p2);
+            ss = __builtin_fma(rx, rx, __builtin_fma(ry, ry, ss));
+        }
+        return ss;
+    };
+    QeifState st;
+    qeif_init(st, p, p.q_inv);
+    const QeifRule rule(p);
+    const QeifNoise noise(p);
+    moments_scale(M, p.q_inv);
+    const double n = p.q_inv * static_cast<double>(N);
+    while (st.k < p.max_it) {
+        if (qeif_moment_iterate(st, M, n, p, rule, noise, exact_ss)) break;
+    }
+    double R[9], t[3];
+    qeif_finish(st, R, t);
+    store_pose(problem, R, t, R_out, t_out);
+    if (res_out) res_out[problem] = static_cast<T>(qeif_residual(st, p.c_inv));
+    if (iters_out) iters_out[problem] = st.k;
+    if (rpy_out) store_rpy(problem, R, rpy_out);
+}
+
 // Points per staging pass of qeif_moment_kernel: 64-byte runs of pixels per problem when every
 // problem brings its own pattern, 128-byte runs when the pattern is shared (more LDS is free).
 template <typename T>
@@ -349,43 +396,152 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment
         }
     }
     if (tid >= nprob) return;  // no barrier follows
+    moment_iterations(M, uv, xyz, xyz_stride, ki, first + tid, N, p, R_out, t_out, res_out, iters_out, rpy_out);
+}
 
-    const int64_t problem = first + tid;
-    const T *my_uv = uv + problem * 2 * N;
-    const T *my_xyz = xyz + problem * xyz_stride;
-    auto exact_ss = [&](const double (&x)[6]) {
-        double phi[9], gamma, ss = 0.0;
-        gamma_matrix(x, phi, gamma);
-        for (int i = 0; i < N; ++i) {
-            const double u = static_cast<double>(my_uv[2 * i]), v = static_cast<double>(my_uv[2 * i + 1]);
-            const double X = static_cast<double>(my_xyz[3 * i]), Y = static_cast<double>(my_xyz[3 * i + 1]);
-            const double Z = static_cast<double>(my_xyz[3 * i + 2]);
-            const double bx = __builtin_fma(ki.a00, u, __builtin_fma(ki.a01, v, ki.a02));
-            const double by = __builtin_fma(ki.a10, u, __builtin_fma(ki.a11, v, ki.a12));
-            const double p1 = __builtin_fma(X, phi[0], __builtin_fma(Y, phi[1], Z * phi[2]));
-            const double p2 = __builtin_fma(X, phi[3], __builtin_fma(Y, phi[4], Z * phi[5]));
-            const double p3 = __builtin_fma(X, phi[6], __builtin_fma(Y, phi[7], Z * phi[8]));
-            const double rx = (bx - x[4]) - __builtin_fma(-bx, p3, p1);
-            const double ry = (by - x[5]) - __builtin_fma(-by, p3, p2);
-            ss = __builtin_fma(rx, rx, __builtin_fma(ry, ry, ss));
-        }
-        return ss;
+// Points of one 128-byte cache line of pixels.
+template <typename T>
+constexpr int kMomentChunkLine = 64 / static_cast<int>(sizeof(T));
+
+// qeif_moment_kernel for per-problem patterns with the staging chunks cut where the cache lines
+// are, and 16-byte pieces all the way from memory to the lane that consumes them.
+// Rows of 2N pixel elements start anywhere in a line, so equal chunks for all problems ask for
+// parts of lines, and the rest of each line is fetched again by the next chunk (measured: the
+// loads of that shape alone reach 3.8 TB/s, 5.2 TB/s in the shape below).  Here a chunk is C = one
+// line of points, and problem j's chunk boundaries are shifted to where its row crosses a line:
+// chunk 0 is points [0, p0_j), chunk t points [p0_j + C (t - 1), p0_j + C t), 1 <= p0_j <= C.  The
+// pattern runs cover the same points.  Lanes of one wavefront therefore consume chunks of
+// different lengths; the sums are formed in the same order as in qeif_moment_kernel and come out
+// identical.
+// Loads are 16-byte pieces through buffer descriptors over the workgroup's rows: a load past their
+// end (rows beyond the batch in the last workgroup, pieces beyond a chunk) returns zeros.  8 lanes
+// share a pixel run and 16 lanes (12 active) a pattern run; the rows one thread loads are BLOCK/8
+// and BLOCK/16 apart, multiples of C, so they share one shift.  A piece that straddles the end of
+// its chunk brings elements of the row's next chunk or of the next row: those are staged and not
+// read.
+// LDS: 20 pieces per problem (8 of pixels, 12 of pattern), piece q of problem j at
+// [q * BLOCK + (j ^ swizzle(q))], 5 C BLOCK elements exactly: with all of the CU's LDS taken by two
+// workgroups there is no room for padding, so the staging writes are spread over the banks by the
+// exclusive-or instead.  A lane reads its problem's pieces whole: five 16-byte reads bring EP
+// points (EP = elements of a piece), a quarter of the LDS instructions of element-wise staging.
+template <typename T>
+__global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment_lines_kernel(
+    const T *__restrict__ uv, const T *__restrict__ xyz, int64_t xyz_stride, KinvRows ki, int64_t B, int N,
+    QeifParams p, T *__restrict__ R_out, T *__restrict__ t_out, T *__restrict__ res_out,
+    int32_t *__restrict__ iters_out, T *__restrict__ rpy_out)
+{
+    constexpr int BLOCK = kMomentBlock<T>, C = kMomentChunkLine<T>;
+    constexpr int EP = 16 / static_cast<int>(sizeof(T));             // elements of a piece = points of a trip
+    constexpr int LU = 2 * C / EP, JU = BLOCK / LU, RU = BLOCK / JU;  // lanes of a pixel run, rows per pass, passes
+    constexpr int LXA = 3 * C / EP, LX = 16, JX = BLOCK / LX, RX = BLOCK / JX;
+    static_assert(LU == 8 && LXA == 12 && BLOCK % 64 == 0 && JU % C == 0 && JX % C == 0 && C % EP == 0, "staging geometry");
+    typedef unsigned piece_t __attribute__((ext_vector_type(4)));
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    piece_t *s_uv = reinterpret_cast<piece_t *>(lds_raw);
+    piece_t *s_xyz = s_uv + LU * BLOCK;
+    // column swizzles: a quarter-wavefront's staging write covers 2 rows times 8 pixel pieces, or one
+    // row times 12 pattern pieces, which the piece index spreads over the 16 slots of an LDS row
+    auto swz_u = [](int q) { return (q << 1) & 15; };
+    auto swz_x = [](int q) { return q & 15; };
+    const int tid = threadIdx.x;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * BLOCK;
+    const int nprob = static_cast<int>(min(static_cast<int64_t>(BLOCK), B - first));
+    const T *uv_blk = uv + first * 2 * N;
+    const T *xyz_blk = xyz + first * xyz_stride;
+    const unsigned row_u = 2u * static_cast<unsigned>(N), row_x = static_cast<unsigned>(xyz_stride);
+    const unsigned stride_u = JU * row_u * static_cast<unsigned>(sizeof(T)), stride_x = JX * row_x * static_cast<unsigned>(sizeof(T));
+    const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T *>(uv_blk), 0, static_cast<int>(static_cast<unsigned>(nprob) * row_u * sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T *>(xyz_blk), 0,
+        static_cast<int>((static_cast<unsigned>(nprob - 1) * row_x + 3u * static_cast<unsigned>(N)) * sizeof(T)), 0x00020000);
+
+    // where row j starts within its line, in points: (u0 + N j) mod C
+    const int u0 = static_cast<int>((reinterpret_cast<uintptr_t>(uv) / (2 * sizeof(T)) + static_cast<uint64_t>(first) * N) &
+                                    (C - 1));
+    auto first_len = [&](int j) { return C - ((u0 + N * j) & (C - 1)); };
+    int p0_min = C;
+    for (int j = 0; j < C; ++j) p0_min = min(p0_min, first_len(j));     // the shifts repeat after C rows at most
+    const int chunks = 1 + (max(0, N - p0_min) + C - 1) / C;
+    auto chunk_start = [&](int p0, int t) { return t == 0 ? 0 : p0 + C * (t - 1); };
+
+    const int ku = tid % LU, ju = tid / LU, kx = tid % LX, jx = tid / LX;
+    const int p0_u = first_len(ju), p0_x = first_len(jx), p0_me = first_len(tid);
+    piece_t pre_uv[RU], pre_xyz[RX];
+    auto prefetch = [&](int t) {
+        // a piece that lies wholly past its row's chunk is given an offset no descriptor covers:
+        // it returns zeros without a memory access
+        // (the whole offset goes in the per-lane operand: the range check does not see the scalar one)
+        const int su = chunk_start(p0_u, t), lu = min(N, p0_u + C * t) - su;
+        const int sx = chunk_start(p0_x, t), lx = min(N, p0_x + C * t) - sx;
+        constexpr unsigned kNowhere = 0xfffffff0u;
+        const bool live_u = EP * ku < 2 * lu, live_x = kx < LXA && EP * kx < 3 * lx;
+        unsigned vu = live_u ? ((static_cast<unsigned>(ju) * row_u + 2u * su) + EP * ku) * static_cast<unsigned>(sizeof(T)) : kNowhere;
+        unsigned vx = live_x ? ((static_cast<unsigned>(jx) * row_x + 3u * sx) + EP * kx) * static_cast<unsigned>(sizeof(T)) : kNowhere;
+        const unsigned du = live_u ? stride_u : 0u, dx = live_x ? stride_x : 0u;
+#pragma unroll
+        for (int r = 0; r < RU; ++r, vu += du) pre_uv[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, vu, 0, 0);
+#pragma unroll
+        for (int r = 0; r < RX; ++r, vx += dx) pre_xyz[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, vx, 0, 0);
     };
-    QeifState st;
-    qeif_init(st, p, p.q_inv);
-    const QeifRule rule(p);
-    const QeifNoise noise(p);
-    moments_scale(M, p.q_inv);
-    const double n = p.q_inv * static_cast<double>(N);
-    while (st.k < p.max_it) {
-        if (qeif_moment_iterate(st, M, n, p, rule, noise, exact_ss)) break;
+    auto commit = [&]() {
+        // The columns are formed at each write (one exclusive-or): as values that stay the same
+        // from chunk to chunk they would be kept in registers, and spilled.  The empty statement
+        // makes the two swizzles look redefined in every pass.
+        int su = swz_u(ku), sx = swz_x(kx);
+        asm volatile("" : "+v"(su), "+v"(sx));
+#pragma unroll
+        for (int r = 0; r < RU; ++r) s_uv[ku * BLOCK + ((ju + r * JU) ^ su)] = pre_uv[r];
+        if (kx < LXA) {
+#pragma unroll
+            for (int r = 0; r < RX; ++r) s_xyz[kx * BLOCK + ((jx + r * JX) ^ sx)] = pre_xyz[r];
+        }
+    };
+    Moments M;
+    moments_clear(M);
+    // EP points are two pieces of pixels and three of pattern.
+    struct Trip {
+        piece_t raw[5];
+    };
+    auto fetch = [&](int trip, Trip &f) {
+        f.raw[0] = s_uv[(2 * trip) * BLOCK + (tid ^ swz_u(2 * trip))];
+        f.raw[1] = s_uv[(2 * trip + 1) * BLOCK + (tid ^ swz_u(2 * trip + 1))];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) f.raw[2 + q] = s_xyz[(3 * trip + q) * BLOCK + (tid ^ swz_x(3 * trip + q))];
+    };
+    auto accumulate = [&](const Trip &f, int left) {
+        T e_uv[2 * EP], e_xyz[3 * EP];
+        __builtin_memcpy(e_uv, &f.raw[0], 32);
+        __builtin_memcpy(e_xyz, &f.raw[2], 48);
+#pragma unroll
+        for (int q = 0; q < EP; ++q) {
+            if (q < left) {
+                const double u = static_cast<double>(e_uv[2 * q]), v = static_cast<double>(e_uv[2 * q + 1]);
+                const double bx = __builtin_fma(ki.a00, u, __builtin_fma(ki.a01, v, ki.a02));
+                const double by = __builtin_fma(ki.a10, u, __builtin_fma(ki.a11, v, ki.a12));
+                moments_add(M, static_cast<double>(e_xyz[3 * q]), static_cast<double>(e_xyz[3 * q + 1]),
+                            static_cast<double>(e_xyz[3 * q + 2]), bx, by);
+            }
+        }
+    };
+    prefetch(0);
+    for (int t = 0; t < chunks; ++t) {
+        __syncthreads();  // the previous chunk has been consumed
+        commit();
+        __syncthreads();
+        if (t + 1 < chunks) prefetch(t + 1);
+        const int start = chunk_start(p0_me, t), cn = max(0, min(N, p0_me + C * t) - start);
+        if (tid < nprob) {
+#pragma unroll 1
+            for (int i = 0; i < cn; i += EP) {
+                Trip f;
+                fetch(i / EP, f);
+                accumulate(f, cn - i);
+            }
+        }
     }
-    double R[9], t[3];
-    qeif_finish(st, R, t);
-    store_pose(problem, R, t, R_out, t_out);
-    if (res_out) res_out[problem] = static_cast<T>(qeif_residual(st, p.c_inv));
-    if (iters_out) iters_out[problem] = st.k;
-    if (rpy_out) store_rpy(problem, R, rpy_out);
+    if (tid >= nprob) return;  // no barrier follows
+    moment_iterations(M, uv, xyz, xyz_stride, ki, first + tid, N, p, R_out, t_out, res_out, iters_out, rpy_out);
 }
 
 template <int LPI, int NCT, typename T>

@@ -21,7 +21,7 @@ def timed(fn, reps=30):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
 for tag, xyz in (("shared", Pd), ("own", own)):
-    for cap in (1, 2, 3, 5, 14):
+    for cap in (1, 14):
         p = pnp.make_params(max_it=cap, rel_tol=0.0 if cap < 14 else 1e-2)
         ms = timed(lambda: pnp.solve_pnp_batch(uv, xyz, K, params=p, want_rpy=False))
         print(tag, "max_it", cap, round(ms, 4), "ms", flush=True)

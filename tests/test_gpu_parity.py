@@ -1189,6 +1189,54 @@ def test_moment_form_at_the_largest_n(torch_dev, moment_form):
         assert np.abs(o["R"] - ref["R"]).max() <= 1e-10 and np.abs(o["t"] - ref["t"]).max() <= 1e-10
 
 
+@pytest.mark.parametrize("N,f64", [(24, False), (33, False), (68, False), (100, False), (12, True), (21, True), (68, True)])
+def test_moment_form_line_cut_staging(torch_dev, moment_form, N, f64):
+    """Per-problem patterns with rows long enough for the staging that cuts its chunks at the
+    128-byte lines of the pixel array.  Where a row crosses a line depends on the address of the
+    array, so the same problems are solved from arrays that start 0 to 5 elements into an
+    allocation, with a pattern stride wider than 3 N, and in batches that end inside a workgroup:
+    the sums are formed in point order whatever the cut, so every result must be bit-identical to
+    the first, which is checked against the point form."""
+    import torch
+    from pnp_solver_test_amd import synth
+    rng = np.random.default_rng(N)
+    P = rng.uniform([-0.07, -0.05, -0.04], [0.07, 0.12, 0.02], (N, 3))
+    B = 777
+    uv, _ = synth.stress_batch(B, seed=N + 1, pattern=P, K=K, is_quantized=True)
+    own = (P[None] + rng.normal(0.0, 0.002, (B, N, 3))).astype(np.float32)
+    uv = np.stack([po.project(own[i].astype(np.float64), K, po.euler_to_R(5.0 * (i % 7) - 15.0, 3.0 * (i % 11) - 15.0, 2.0 * (i % 5), True),
+                              np.array([0.01 * (i % 3), -0.02, 0.5 + 0.01 * (i % 40)]), True) for i in range(B)]).astype(np.float32)
+    dt = torch.float64 if f64 else torch.float32
+    entry = moment_form.pnp_qeif_batch_f64 if f64 else moment_form.pnp_qeif_batch_f32
+    uv_t, own_t = torch.from_numpy(uv).to(torch_dev, dt), torch.from_numpy(own).to(torch_dev, dt)
+
+    def run(off, stride, nb):
+        flat_uv = torch.zeros(nb * 2 * N + 8, device=torch_dev, dtype=dt)
+        flat_uv[off:off + nb * 2 * N] = uv_t[:nb].reshape(-1)
+        wide = torch.zeros(nb * stride + 8, device=torch_dev, dtype=dt)
+        wide[off:off + nb * stride].view(nb, stride)[:, :3 * N] = own_t[:nb].reshape(nb, 3 * N)
+        R = torch.full((nb, 9), 7.0, device=torch_dev, dtype=dt)
+        t = torch.full((nb, 3), 7.0, device=torch_dev, dtype=dt)
+        it = torch.full((nb,), -1, device=torch_dev, dtype=torch.int32)
+        _lib.check(entry(flat_uv[off:].data_ptr(), wide[off:].data_ptr(), stride, _lib.k_array(K), nb, N, None,
+                         R.data_ptr(), t.data_ptr(), None, it.data_ptr(), None, _lib.PTR_DEVICE,
+                         torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        return R.cpu().numpy(), t.cpu().numpy(), it.cpu().numpy()
+
+    R0, t0, it0 = run(0, 3 * N, B)
+    for off, stride, nb in ((1, 3 * N, B), (2, 3 * N + 1, B), (3, 3 * N + 5, B), (5, 4 * N, B), (4, 3 * N, 1), (0, 3 * N, 255),
+                            (1, 3 * N + 2, 257), (2, 3 * N, 512)):
+        R, t, it = run(off, stride, nb)
+        assert np.array_equal(R, R0[:nb]) and np.array_equal(t, t0[:nb]) and np.array_equal(it, it0[:nb]), (off, stride, nb)
+    moment_form.pnp_set_qeif_form(_lib.QEIF_FORM_POINTS)
+    solve = solve_dev64 if f64 else solve_dev
+    ref = solve(uv, own, torch_dev)
+    assert np.array_equal(it0, ref["iters"])
+    tol = 1e-10 if f64 else 2e-7
+    assert np.abs(R0.reshape(B, 3, 3) - ref["R"]).max() <= tol and np.abs(t0 - ref["t"]).max() <= tol
+
+
 def test_moment_form_selection_rules(torch_dev):
     lib = _lib.load()
     assert lib.pnp_get_qeif_form(1 << 18, 68) == _lib.QEIF_FORM_MOMENTS
