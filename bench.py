@@ -29,6 +29,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -45,6 +46,7 @@ N_POINTS = 6
 
 SAMPLE_EVERY = 8     # every 8th timed launch is bracketed by an event pair of its own
 SPINUP_MS = 60.0     # every measurement is preceded by at least this much untimed GPU work
+GATHER_DEADLINE_S = 120   # N > 1: the optional result exchange may take this long, then the line goes out without it
 
 
 def spin_up(torch, fn, min_ms=SPINUP_MS):
@@ -243,6 +245,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="problems per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-c-abi-gather", action="store_true",
+                    help="N > 1: time the result exchange through torch.distributed only")
     ap.add_argument("--launcher-check", action="store_true",
                     help="run only the N-rank plumbing on the gloo backend (no GPU, no solver)")
     args = ap.parse_args()
@@ -336,54 +340,7 @@ def main():
     iters_mean = float(out["iters"].float().mean().item())
     ok = bool(torch.isfinite(out["R"]).all().item())
 
-    # The optional exchange: every rank ends up with every rank's poses (R, t: 48 B per problem)
-    # through RCCL all-gather.  Reported beside the headline, never part of it.
-    gather = None
-    if distributed:
-        g_steps = max(5, args.steps // 10)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(g_steps):
-            o = step()
-            full = pnp.gather_results({"R": o["R"], "t": o["t"]})
-        barrier()
-        g_elapsed = time.perf_counter() - t0
-        gmax = torch.tensor([g_elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(gmax, op=dist.ReduceOp.MAX)
-        gather = dict(solves_per_s=round(world * B * g_steps / float(gmax.item()), 1), steps=g_steps,
-                      ms_per_step=round(float(gmax.item()) / g_steps * 1e3, 4),
-                      gathered_bytes_per_rank_per_step=int(full["R"].numel() * 4 + full["t"].numel() * 4),
-                      what="solve + all_gather_into_tensor of R and t (RCCL)")
-        # the same with the poses collected on rank 0 only
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(g_steps):
-            o = step()
-            pnp.gather_results({"R": o["R"], "t": o["t"]}, dst=0)
-        barrier()
-        gmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        dist.all_reduce(gmax, op=dist.ReduceOp.MAX)
-        gather["to_rank_0_only"] = dict(solves_per_s=round(world * B * g_steps / float(gmax.item()), 1),
-                                        ms_per_step=round(float(gmax.item()) / g_steps * 1e3, 4),
-                                        what="solve + gather of R and t to rank 0 (RCCL)")
-        # and through the C ABI (pnp_gather_results on a communicator of the library's own)
-        comm = pnp.RcclComm.from_torch_group()
-        try:
-            for tag, dst in (("c_abi_all_gather", None), ("c_abi_to_rank_0_only", 0)):
-                pnp.gather_results({"R": out["R"], "t": out["t"]}, dst=dst, comm=comm)
-                barrier()
-                t0 = time.perf_counter()
-                for _ in range(g_steps):
-                    o = step()
-                    pnp.gather_results({"R": o["R"], "t": o["t"]}, dst=dst, comm=comm)
-                barrier()
-                gmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-                dist.all_reduce(gmax, op=dist.ReduceOp.MAX)
-                gather[tag] = dict(solves_per_s=round(world * B * g_steps / float(gmax.item()), 1),
-                                   ms_per_step=round(float(gmax.item()) / g_steps * 1e3, 4))
-        finally:
-            comm.close()
-
+    line = None
     if rank == 0:
         total = world * B * args.steps
         value = total / elapsed
@@ -455,8 +412,6 @@ def main():
                 "flops_per_solve": round(flops, 1),
             },
         }
-        if gather is not None:
-            line["with_result_gather"] = gather
         if world == 1 and not args.no_other_configs:
             other = {}
             n_small = max(5, min(50, args.steps // 2))
@@ -541,11 +496,74 @@ def main():
             line["cpu_baseline_c"] = cpu_baseline_c(uv_h, xyz_h, K)
             threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
             line["cpu_baseline_c_all_cores"] = cpu_baseline_c_threads(uv_h, xyz_h, K, threads)
-        print(json.dumps(line), flush=True)
 
+    # The optional exchange of results (R, t: 48 B per problem), reported beside the headline and
+    # never part of it.  It runs after everything the line needs has been measured, each variant
+    # on its own (one that fails is reported as an error string), and under a deadline: if a
+    # collective never returns, rank 0 prints the line without it and every rank leaves.
     if distributed:
+        printed = []
+
+        def bail():
+            if rank == 0 and not printed:
+                line["with_result_gather"] = dict(gather, error="did not finish within %d s" % GATHER_DEADLINE_S)
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        gather = {}
+        watchdog = threading.Timer(GATHER_DEADLINE_S, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        g_steps = max(5, args.steps // 10)
+
+        def timed_exchange(exchange):
+            exchange(out)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(g_steps):
+                exchange(step())
+            barrier()
+            gmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(gmax, op=dist.ReduceOp.MAX)
+            return dict(solves_per_s=round(world * B * g_steps / float(gmax.item()), 1), steps=g_steps,
+                        ms_per_step=round(float(gmax.item()) / g_steps * 1e3, 4))
+
+        variants = [("all_gather", "solve + all_gather_into_tensor of R and t (RCCL through torch.distributed)",
+                     lambda o: pnp.gather_results({"R": o["R"], "t": o["t"]})),
+                    ("to_rank_0_only", "solve + gather of R and t to rank 0 (RCCL through torch.distributed)",
+                     lambda o: pnp.gather_results({"R": o["R"], "t": o["t"]}, dst=0))]
+        comm = None
+        if not args.no_c_abi_gather:
+            try:
+                comm = pnp.RcclComm.from_torch_group()
+                variants += [("c_abi_all_gather", "the same through pnp_gather_results on a communicator of the library's own",
+                              lambda o: pnp.gather_results({"R": o["R"], "t": o["t"]}, comm=comm)),
+                             ("c_abi_to_rank_0_only", "pnp_gather_results with a root",
+                              lambda o: pnp.gather_results({"R": o["R"], "t": o["t"]}, dst=0, comm=comm))]
+            except Exception as e:          # noqa: BLE001 - reported, the headline stands
+                gather["c_abi_error"] = "%s: %s" % (type(e).__name__, e)
+        for tag, what, exchange in variants:
+            try:
+                gather[tag] = dict(timed_exchange(exchange), what=what)
+            except Exception as e:          # noqa: BLE001
+                gather[tag] = dict(error="%s: %s" % (type(e).__name__, e))
+                break                        # the ranks may no longer agree on what comes next
+        if comm is not None:
+            try:
+                comm.close()
+            except Exception:               # noqa: BLE001
+                pass
+        gather["gathered_bytes_per_rank_per_step"] = world * B * 48
+        if rank == 0:
+            line["with_result_gather"] = gather
+            print(json.dumps(line), flush=True)
+            printed.append(True)
+        # still under the deadline: a rank that gave up on an exchange must not wait here for good
         dist.barrier()
         dist.destroy_process_group()
+        watchdog.cancel()
+    elif rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
