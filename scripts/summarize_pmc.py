@@ -13,7 +13,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", "pmc")
 
 # dispatch order of scripts/pmc_probe.py: 3 launches each
@@ -21,7 +21,7 @@ LAUNCHES = [("qeif_n6_b1m_per_problem_xyz", "qeif_kernel<1, 6,", 1 << 20, 6, Tru
             ("dlt_n6_b1m_per_problem_xyz", "dlt_kernel<1, 6,", 1 << 20, 6, True),
             ("qeif_n6_b1m_shared_pattern", "qeif_kernel<1, 6,", 1 << 20, 6, False),
             ("qeif_n68_b256k_shared_pattern", "qeif_moment_kernel<float, 16, true>", 1 << 18, 68, False),
-            ("qeif_n68_b256k_per_problem_xyz", "qeif_moment_kernel<float, 8, false>", 1 << 18, 68, True)]
+            ("qeif_n68_b256k_per_problem_xyz", "qeif_moment_lines_kernel<float>", 1 << 18, 68, True)]
 
 
 def load(name):
@@ -67,7 +67,7 @@ for label, kern, B, N, own in LAUNCHES:
     s["write_bytes"] = s["WRITE_SIZE"] * 1024
     s["hbm_bytes_per_launch"] = s["fetch_bytes_2x"] + s["write_bytes"]
     s["fetch_2x_over_input"] = round(s["fetch_bytes_2x"] / in_bytes, 4)
-    if "moment" in kern:
+    if "qeif_moment_kernel" in kern:
         # The moment kernel reads 4 bytes per lane in runs of 2C pixel floats / 3C pattern floats per
         # problem row; FETCH_SIZE counts such reads neither at 1/2 (the 16-bytes-per-lane rule) nor
         # at 1.  scripts/probes/fetch_calibration.hip reads a known byte count once in each of
@@ -84,6 +84,16 @@ for label, kern, B, N, own in LAUNCHES:
         s["fetch_bytes_calibrated"] = ratio * in_bytes
         s["hbm_bytes_per_launch"] = s["fetch_bytes_calibrated"] + s["write_bytes"]
         del s["fetch_bytes_2x"], s["fetch_2x_over_input"]
+    if "qeif_moment_lines_kernel" in kern:
+        # 16-byte pieces: pixel runs are whole 128-byte lines (counted at half, like any wide read),
+        # pattern runs are 192 bytes at multiples of 64, i.e. one 128-byte and one 64-byte request, and
+        # the calibration probe shows short requests counted at more than half (0.77 of the bytes for
+        # 64-byte runs).  2 x FETCH_SIZE therefore over-counts the pattern half of the input by up to
+        # a third; the figure is kept as an upper bound.
+        s["fetch_calibration"] = ("2 x FETCH_SIZE is an upper bound for this kernel: its 64-byte requests (a third of "
+                                  "the pattern bytes) are counted at more than half")
+        uv_b, xyz_b = B * 8 * N, B * 12 * N
+        s["fetch_2x_if_read_once_with_64B_requests_counted_in_full"] = round((uv_b + xyz_b * 4.0 / 3.0) / in_bytes, 4)
     if "SQ_ACTIVE_INST_VALU" in s and "GRBM_GUI_ACTIVE" in s:
         # SQ_* activity counters tick in quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs
         s["valu_busy_frac"] = round(4 * s["SQ_ACTIVE_INST_VALU"] / 1024 / (s["GRBM_GUI_ACTIVE"] / 8), 4)
