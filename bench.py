@@ -161,6 +161,23 @@ def cpu_baseline_c_threads(uv, xyz, K, threads):
                        "slice, %.2f s" % (n, threads, dt))
 
 
+def cpu_baseline_numpy_batched(uv, xyz, K):
+    """The same recurrence in array operations over many problems at once (what a NumPy user
+    would write instead of the per-problem loop), chunks of 32 768 problems for about 5 s."""
+    from oracle import pnp_oracle as po
+    chunk, n = 1 << 15, 0
+    po.qeif_solve_batch(uv[:256].astype(np.float64), xyz[:256].astype(np.float64), K)
+    t0 = time.perf_counter()
+    while n < len(uv) and (time.perf_counter() - t0 < 5.0 or n == 0):
+        m = min(chunk, len(uv) - n)
+        po.qeif_solve_batch(uv[n:n + m].astype(np.float64), xyz[n:n + m].astype(np.float64), K)
+        n += m
+    dt = time.perf_counter() - t0
+    return dict(value=round(n / dt, 1), unit="solves/s", cores=1, kind="port",
+                sample="first %d problems in chunks of %d, NumPy float64 array operations over the batch "
+                       "(oracle/pnp_oracle.qeif_solve_batch), one process, %.1f s" % (n, chunk, dt))
+
+
 def cpu_baseline_c(uv, xyz, K):
     """Same sample idea with the scalar C restatement (oracle/pnp_oracle.c), one core."""
     from oracle import c_oracle
@@ -493,6 +510,7 @@ def main():
             line["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:   # last: the GPU idles (and clocks down) meanwhile
             line["cpu_baseline"] = cpu_baseline(uv_h, xyz_h, K)
+            line["cpu_baseline_numpy_batched"] = cpu_baseline_numpy_batched(uv_h, xyz_h, K)
             line["cpu_baseline_c"] = cpu_baseline_c(uv_h, xyz_h, K)
             threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
             line["cpu_baseline_c_all_cores"] = cpu_baseline_c_threads(uv_h, xyz_h, K, threads)

@@ -243,6 +243,80 @@ def qeif_solve(uv, P, K=K_DEFAULT, **params):
                 iters=k, x=x)
 
 
+def qeif_solve_batch(uv, P, K=K_DEFAULT, **params):
+    """qeif_solve over a batch in array operations: what a NumPy user of the reference would
+    write to solve many problems at once on the CPU (the same recurrence, :2771-3025, problems
+    that have met the stopping rule drop out of the arrays).  uv (B,N,2); P (N,3) or (B,N,3).
+    The 6x6 inverses are numpy.linalg.inv on stacks where qeif_solve follows the reference's
+    pinv; the matrices are well conditioned, results agree to round-off.  Returns R (B,3,3),
+    t (B,3), res_norm (B,), iters (B,), x (B,6)."""
+    p = dict(QEIF_DEFAULTS)
+    p.update(params)
+    uv = np.asarray(uv, dtype=np.float64)
+    B, n = uv.shape[0], uv.shape[1]
+    P = np.asarray(P, dtype=np.float64)
+    Pb = np.broadcast_to(P, (B, n, 3))
+    K_inv = np.linalg.inv(K)
+    nu = np.concatenate([uv, np.ones((B, n, 1))], axis=2) @ K_inv.T
+    Bx, By = nu[:, :, 0], nu[:, :, 1]
+    z = np.concatenate([Bx, By], axis=1)                               # (B,2N)
+    R_proc = np.diag([p["r_quat"]] * 4 + [p["r_delta"]] * 2)
+    x = np.zeros((B, 6))
+    x[:, 0] = 1.0
+    Sigma = np.broadcast_to(np.eye(6) / p["omega0"], (B, 6, 6)).copy()
+    res_old = np.full(B, p["res_old0"])
+    res_norm = np.full(B, 10.0 ** 5)
+    iters = np.zeros(B, dtype=np.int32)
+    live = np.arange(B)
+    ones, zeros = np.ones((1, n, 1)), np.zeros((1, n, 1))
+    for k in range(1, p["max_it"] + 1):
+        if live.size == 0:
+            break
+        xa, Pa, bx, by = x[live], Pb[live], Bx[live], By[live]
+        m = live.size
+        Obar = np.linalg.inv(Sigma[live] + R_proc)
+        zeta = (Obar @ xa[:, :, None])[:, :, 0]
+        qr, qi, qj, qk = xa[:, 0], xa[:, 1], xa[:, 2], xa[:, 3]
+        gamma = qr * qr + qi * qi + qj * qj + qk * qk
+        phi1 = np.stack([gamma - 2 * (qj * qj + qk * qk), 2 * (qi * qj - qr * qk), 2 * (qi * qk + qr * qj)], axis=1)
+        phi2 = np.stack([2 * (qi * qj + qr * qk), gamma - 2 * (qi * qi + qk * qk), 2 * (qj * qk - qr * qi)], axis=1)
+        phi3 = np.stack([2 * (qi * qk - qr * qj), 2 * (qj * qk + qr * qi), gamma - 2 * (qi * qi + qj * qj)], axis=1)
+        a, b, c, d = 2.0 * qr, 2.0 * qi, 2.0 * qj, 2.0 * qk
+        Q1 = np.stack([np.stack([a, b, -c, -d], 1), np.stack([-d, c, b, -a], 1), np.stack([c, d, a, b], 1)], axis=1)
+        Q2 = np.stack([np.stack([d, c, b, a], 1), np.stack([a, -b, c, -d], 1), np.stack([-b, -a, d, c], 1)], axis=1)
+        Q3 = np.stack([np.stack([-c, d, -a, b], 1), np.stack([b, a, d, c], 1), np.stack([a, -b, -c, d], 1)], axis=1)
+        P1 = (Pa @ phi1[:, :, None])[:, :, 0]
+        P2 = (Pa @ phi2[:, :, None])[:, :, 0]
+        P3 = (Pa @ phi3[:, :, None])[:, :, 0]
+        h = np.concatenate([P1 - bx * P3 + xa[:, 4:5], P2 - by * P3 + xa[:, 5:6]], axis=1)
+        PQ3 = Pa @ Q3
+        one, zero = np.broadcast_to(ones, (m, n, 1)), np.broadcast_to(zeros, (m, n, 1))
+        H = np.concatenate([np.concatenate([Pa @ Q1 - bx[:, :, None] * PQ3, one, zero], axis=2),
+                            np.concatenate([Pa @ Q2 - by[:, :, None] * PQ3, zero, one], axis=2)], axis=1)   # (m,2N,6)
+        Ht = np.swapaxes(H, 1, 2)
+        r = z[live] - h
+        Omega = Obar + p["q_inv"] * (Ht @ H)
+        zeta = zeta + p["q_inv"] * (Ht @ (r + (H @ xa[:, :, None])[:, :, 0])[:, :, None])[:, :, 0]
+        res = np.linalg.norm(r, axis=1)
+        Sig = np.linalg.inv(Omega)
+        x[live] = (Sig @ zeta[:, :, None])[:, :, 0]
+        Sigma[live] = Sig
+        res_norm[live] = res
+        iters[live] = k
+        go_on = ~(np.abs((res - res_old[live]) / res_old[live]) < p["rel_tol"])
+        res_old[live] = res
+        live = live[go_on]
+    q = x[:, 0:4]
+    qr, qi, qj, qk = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    gamma = np.sum(q * q, axis=1)
+    R = np.stack([np.stack([gamma - 2 * (qj * qj + qk * qk), 2 * (qi * qj - qr * qk), 2 * (qi * qk + qr * qj)], 1),
+                  np.stack([2 * (qi * qj + qr * qk), gamma - 2 * (qi * qi + qk * qk), 2 * (qj * qk - qr * qi)], 1),
+                  np.stack([2 * (qi * qk - qr * qj), 2 * (qj * qk + qr * qi), gamma - 2 * (qi * qi + qj * qj)], 1)],
+                 axis=1) / gamma[:, None, None]
+    t = np.stack([x[:, 4], x[:, 5], np.ones(B)], axis=1) / gamma[:, None]
+    return dict(R=R, t=t, res_norm=res_norm, iters=iters, x=x)
+
+
 # ---------------------------------------------------------------------------
 # Iterated linear DLT with closed-form block reconstruction
 # ---------------------------------------------------------------------------

@@ -113,6 +113,26 @@ def test_qeif_n15_and_a_second_68_point_pattern(golden):
     assert np.abs(r["rpy"] - rpy_of(b)).max() < 1e-8
 
 
+def test_numpy_batched_restatement(golden):
+    """The array-operation form of the NumPy oracle (the bench's second CPU baseline) against the
+    reference's results: same iteration counts, poses to round-off, both pattern layouts."""
+    g = golden("stress_qeif_n6")
+    uv = g["uv15"][:3000, lm6_indices(g), :].astype(np.float64)
+    r = po.qeif_solve_batch(uv, P6, K)
+    assert np.array_equal(r["iters"], g["iters"][:3000])
+    assert np.abs(r["R"] - g["R"][:3000]).max() < 1e-10 and np.abs(r["t"] - g["t"][:3000]).max() < 1e-10
+    assert np.abs(r["res_norm"] - g["res_norm"][:3000]).max() < 1e-11
+    own = np.broadcast_to(P6, (3000, 6, 3))
+    assert np.array_equal(po.qeif_solve_batch(uv, own, K)["R"], r["R"])
+    b = golden("qeif_n68_b")
+    r = po.qeif_solve_batch(b["uv"].astype(np.float64), b["xyz"], K)
+    assert np.array_equal(r["iters"], b["iters"]) and np.abs(r["R"] - b["R"]).max() < 1e-10
+    five = po.qeif_solve_batch(uv[:50], P6, K, max_it=5, rel_tol=0.0)
+    assert np.all(five["iters"] == 5)
+    for i in (0, 7, 49):
+        assert np.abs(five["R"][i] - po.qeif_solve(uv[i], P6, K, max_it=5, rel_tol=0.0)["R"]).max() < 1e-11
+
+
 def test_qeif_per_problem_patterns_equal_shared(golden):
     g = golden("stress_qeif_n6")
     uv = g["uv15"][:64, lm6_indices(g), :].astype(np.float64)
