@@ -29,7 +29,7 @@ def oracle_threads(fn, uv, P):
     n = len(uv)
     bounds = [(i * n // THREADS, (i + 1) * n // THREADS) for i in range(THREADS)]
     with ThreadPoolExecutor(THREADS) as ex:
-        parts = list(ex.map(lambda b: fn(uv[b[0]:b[1]], P, K), bounds))
+        parts = list(ex.map(lambda b: fn(uv[b[0]:b[1]], P[b[0]:b[1]] if P.ndim == 3 else P, K), bounds))
     return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
 
 
@@ -87,5 +87,22 @@ for tag, N, B, quant in cases:
                          "discontinuity at k2 = 0): %d of %d problems left out" % (int((~both).sum()), len(both)))
             report["cases"]["dlt_n6_b1m_quantised_%s" % flavour] = r
             print("dlt", flavour, r, flush=True)
+# a pattern of its own per problem (the golden 68 points moved by a few millimetres), pixels of
+# that very pattern: the moment form's staging that cuts its chunks at the cache lines
+B, N = 1 << 18, 68
+rng = np.random.default_rng(7)
+own = (synth.face68()[None] + rng.normal(0.0, 0.003, (B, N, 3))).astype(np.float32)
+uv = np.empty((B, N, 2), np.float32)
+roll, pitch, yaw, t = synth.sample_stress_poses(np.random.default_rng(8), B)
+for lo in range(0, B, 1 << 15):
+    hi = lo + (1 << 15)
+    R = synth.rotation_from_euler_deg(roll[lo:hi], yaw[lo:hi], pitch[lo:hi])
+    uv[lo:hi] = synth.project(own[lo:hi], K, R, t[lo:hi], True)
+for flavour, dt in (("f32", np.float32), ("f64", np.float64)):
+    ref = oracle_threads(c_oracle.qeif_batch, uv.astype(np.float64), own.astype(np.float64))
+    out = pnp.solve_pnp_batch(torch.from_numpy(uv.astype(dt)).to(dev), torch.from_numpy(own.astype(dt)).to(dev), K)
+    torch.cuda.synchronize()
+    report["cases"]["qeif_n68_b256k_per_problem_patterns_%s" % flavour] = compare(out, ref)
+    print("n68 per-problem", flavour, report["cases"]["qeif_n68_b256k_per_problem_patterns_%s" % flavour], flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(report, open(os.path.join(ROOT, "gpurun_out", "parity_report.json"), "w"), indent=1)
