@@ -1382,6 +1382,39 @@ def test_every_problem_of_the_headline_batch_against_the_oracle(torch_dev):
         assert np.abs(out["rpy_deg"] - ref["rpy"]).max() <= 5e-4
 
 
+def test_every_problem_of_the_n68_batch_with_a_pattern_per_problem(torch_dev):
+    """Config 4 as the data layout has it: 262,144 problems of 68 points, each with its own
+    pattern (the synthetic face moved by millimetres) and the pixels of that pattern, float32
+    arrays: every problem against the C oracle on the host's threads."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    from pnp_solver_test_amd import synth
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    B, N = 1 << 18, 68
+    rng = np.random.default_rng(7)
+    own = (synth.face68()[None] + rng.normal(0.0, 0.003, (B, N, 3))).astype(np.float32)
+    roll, pitch, yaw, t = synth.sample_stress_poses(np.random.default_rng(8), B)
+    uv = np.empty((B, N, 2), np.float32)
+    for lo in range(0, B, 1 << 15):
+        hi = lo + (1 << 15)
+        uv[lo:hi] = synth.project(own[lo:hi], K, synth.rotation_from_euler_deg(roll[lo:hi], yaw[lo:hi], pitch[lo:hi]),
+                                  t[lo:hi], True)
+    bounds = [(i * B // threads, (i + 1) * B // threads) for i in range(threads)]
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(lambda b: c_oracle.qeif_batch(uv[b[0]:b[1]].astype(np.float64),
+                                                          own[b[0]:b[1]].astype(np.float64), K), bounds))
+    ref = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    out = pnp.solve_pnp_batch(torch.from_numpy(uv).to(torch_dev), torch.from_numpy(own).to(torch_dev), K)
+    torch.cuda.synchronize()
+    out = to_np(out)
+    assert _lib.load().pnp_get_qeif_form(B, N) == _lib.QEIF_FORM_MOMENTS
+    assert np.array_equal(out["iters"], ref["iters"])
+    assert np.abs(out["R"].astype(np.float64) - ref["R"]).max() <= DR_TIGHT
+    assert rel_t(out["t"], ref["t"]).max() <= RELT_TIGHT
+    assert rot_angle(out["R"], ref["R"]).max() <= 2e-7
+
+
 def test_every_problem_of_the_dlt_batch_against_the_oracle(torch_dev):
     """Config 2 at full size: 1,048,576 six-point problems through the iterated DLT, every one of
     them against the C oracle, float32 and float64 arrays, with no branch-margin mask: what is
