@@ -261,6 +261,31 @@ bool use_moment_form(int64_t B, int N, int n_patterns)
     return g_forced_lpi.load() == 0 && N >= kMomentMinPoints && B >= kMomentMinBatch;
 }
 
+// LDS of qeif_moment_lines_kernel<T>: more than a kernel may take without being allowed to, which
+// is done once per device (on pnp_init, or else on the first launch that wants the kernel).
+template <typename T>
+constexpr size_t lines_kernel_lds()
+{
+    return static_cast<size_t>(5) * pnp::kMomentChunkLine<T> * pnp::kMomentBlock<T> * sizeof(T);
+}
+
+template <typename T>
+bool lines_kernel_allowed()
+{
+    static std::atomic<uint64_t> allowed{0}, refused{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const uint64_t bit = uint64_t(1) << (dev & 63);
+    if (!((allowed.load() | refused.load()) & bit)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pnp::qeif_moment_lines_kernel<T>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(lines_kernel_lds<T>()));
+        if (e != hipSuccess) (void)hipGetLastError();
+        (e == hipSuccess ? allowed : refused).fetch_or(bit);
+    }
+    return (allowed.load() & bit) != 0;
+}
+
 template <typename T>
 int launch_qeif_moment(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, const pnp::KinvRows &ki,
                        int64_t B, int N, const pnp::QeifParams &p, T *R, T *t, T *res, int32_t *iters, T *rpy)
@@ -283,26 +308,14 @@ int launch_qeif_moment(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_str
             hipLaunchKernelGGL((pnp::qeif_moment_kernel<T, c_own, true>), grid, dim3(block), lds_short, s, uv, xyz,
                                xyz_stride, ki, B, N, p, R, t, res, iters, rpy);
     } else {
-        // chunks cut at the cache lines: all of a CU's LDS between two workgroups, which a kernel
-        // has to be allowed once per device
-        constexpr size_t lines_lds = static_cast<size_t>(5) * pnp::kMomentChunkLine<T> * block * sizeof(T);
-        static std::atomic<uint64_t> allowed{0}, refused{0};
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        const uint64_t bit = uint64_t(1) << (dev & 63);
-        if (!((allowed.load() | refused.load()) & bit)) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pnp::qeif_moment_lines_kernel<T>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     static_cast<int>(lines_lds));
-            if (e != hipSuccess) (void)hipGetLastError();
-            (e == hipSuccess ? allowed : refused).fetch_or(bit);
-        }
-        const hipError_t lines_ready = (allowed.load() & bit) ? hipSuccess : hipErrorInvalidValue;
+        // chunks cut at the cache lines: all of a CU's LDS between two workgroups
+        constexpr size_t lines_lds = lines_kernel_lds<T>();
+        const bool lines_ready = lines_kernel_allowed<T>();
         // its loads address a workgroup's rows through 32-bit byte offsets
         const bool offsets_fit = static_cast<uint64_t>(block) * static_cast<uint64_t>(xyz_stride) * sizeof(T) < (uint64_t(1) << 31);
         // measured on 256k-512k problems: ahead from about 24 float32 (12 float64) points per problem
         const bool long_rows = static_cast<size_t>(N) * sizeof(T) >= 96;
-        if (lines_ready == hipSuccess && offsets_fit && long_rows && !g_moment_plain.load()) {
+        if (lines_ready && offsets_fit && long_rows && !g_moment_plain.load()) {
             hipLaunchKernelGGL((pnp::qeif_moment_lines_kernel<T>), grid, dim3(block), lines_lds, s, uv, xyz, xyz_stride, ki,
                                B, N, p, R, t, res, iters, rpy);
         } else {
@@ -992,6 +1005,8 @@ int pnp_init(int device)
     // this device's address of the static staging array, so that the allocation-free entry point
     // finds it resolved
     if (device >= kMaxDevices) return fail(PNP_E_HIP, "device index %d out of range", device);
+    (void)lines_kernel_allowed<float>();
+    (void)lines_kernel_allowed<double>();
     std::lock_guard<std::mutex> lock(g_scratch[device].mu);
     void *unused = nullptr;
     return scratch_address(device, &unused);
