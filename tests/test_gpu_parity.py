@@ -1237,6 +1237,45 @@ def test_moment_form_line_cut_staging(torch_dev, moment_form, N, f64):
     assert np.abs(R0.reshape(B, 3, 3) - ref["R"]).max() <= tol and np.abs(t0 - ref["t"]).max() <= tol
 
 
+def test_line_cut_staging_equals_equal_chunk_staging(torch_dev, tmp_path):
+    """The two staging schemes of the moment form (per-problem patterns) form their sums in the
+    same order: a second process that keeps the equal-chunk kernel (PNP_MOMENT_PLAIN=1 is read when
+    the library is loaded) must return the same bits."""
+    import os
+    import subprocess
+    import sys
+    from pnp_solver_test_amd import synth
+    rng = np.random.default_rng(11)
+    cases = {}
+    for N, B in ((32, 1500), (68, 1100)):
+        P = rng.uniform([-0.07, -0.05, -0.04], [0.07, 0.12, 0.02], (N, 3))
+        uv, _ = synth.stress_batch(B, seed=N, pattern=P, K=K, is_quantized=True)
+        cases[N] = (uv, np.ascontiguousarray(np.broadcast_to(P.astype(np.float32), (B, N, 3))))
+    np.savez(tmp_path / "in.npz", **{"uv%d" % n: c[0] for n, c in cases.items()}, **{"xyz%d" % n: c[1] for n, c in cases.items()})
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import pnp_solver_test_amd as pnp\n"
+        "from pnp_solver_test_amd import _lib, synth\n"
+        "_lib.load().pnp_set_qeif_form(_lib.QEIF_FORM_MOMENTS)\n"
+        "d = np.load(%r); out = {}\n"
+        "for n in (32, 68):\n"
+        "    for tag, dt in (('f32', torch.float32), ('f64', torch.float64)):\n"
+        "        o = pnp.solve_pnp_batch(torch.from_numpy(d['uv%%d' %% n]).cuda().to(dt), torch.from_numpy(d['xyz%%d' %% n]).cuda().to(dt), synth.K_DEFAULT)\n"
+        "        out['R%%d%%s' %% (n, tag)] = o['R'].cpu().numpy(); out['t%%d%%s' %% (n, tag)] = o['t'].cpu().numpy(); out['i%%d%%s' %% (n, tag)] = o['iters'].cpu().numpy()\n"
+        "np.savez(sys.argv[1], **out)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "in.npz"))
+    outs = {}
+    for tag, env in (("lines", {}), ("plain", {"PNP_MOMENT_PLAIN": "1"})):
+        path = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(path)
+    assert sorted(outs["lines"].files) == sorted(outs["plain"].files) and len(outs["lines"].files) == 12
+    for k in outs["lines"].files:
+        assert np.array_equal(outs["lines"][k], outs["plain"][k]), k
+
+
 def test_moment_form_selection_rules(torch_dev):
     lib = _lib.load()
     assert lib.pnp_get_qeif_form(1 << 18, 68) == _lib.QEIF_FORM_MOMENTS
