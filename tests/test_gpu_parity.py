@@ -1310,6 +1310,38 @@ def test_cpp_consumer_of_the_c_abi(torch_dev):
     assert "abi_check passed" in r.stdout
 
 
+def test_device_pointer_calls_can_be_captured_in_a_graph(golden, torch_dev):
+    """The device-pointer entry points allocate nothing, synchronise nothing and launch on the
+    stream they are given, so a HIP graph can capture them: captured once, replayed on new
+    pixels in the same buffers, against direct calls.  QEIF (six points), DLT, and the moment
+    form with a pattern per problem (its kernel's LDS allowance is set up before the capture)."""
+    import torch
+    from pnp_solver_test_amd import synth
+    g, uv6 = stress_uv6(golden)
+    P68 = synth.face68()
+    uv68, _ = synth.stress_batch(4096, seed=3, pattern=P68, K=K, is_quantized=True)
+    own68 = np.ascontiguousarray(np.broadcast_to(P68.astype(np.float32), (4096, 68, 3)))
+    cases = [("qeif", uv6[:4096], np.ascontiguousarray(np.broadcast_to(P6f, (4096, 6, 3)))),
+             ("dlt", uv6[:4096], np.ascontiguousarray(np.broadcast_to(P6f, (4096, 6, 3)))),
+             ("qeif", uv68, own68)]
+    for method, uv, xyz in cases:
+        uv_d, xyz_d = to_dev(uv, torch_dev), to_dev(xyz, torch_dev)
+        pnp.solve_pnp_batch(uv_d, xyz_d, K, method=method)          # first use outside the capture
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = pnp.solve_pnp_batch(uv_d, xyz_d, K, method=method)
+        other = np.ascontiguousarray(uv[::-1])
+        uv_d.copy_(to_dev(other, torch_dev))
+        xyz_d.copy_(to_dev(np.ascontiguousarray(xyz[::-1]), torch_dev))
+        graph.replay()
+        torch.cuda.synchronize()
+        got = to_np(out)
+        want = solve_dev(other, np.ascontiguousarray(xyz[::-1]), torch_dev, method=method)
+        for k in ("R", "t", "res_norm"):
+            assert np.array_equal(got[k], want[k], equal_nan=True), (method, uv.shape, k)
+
+
 def test_launch_on_a_side_stream(golden, torch_dev):
     """Device-pointer calls enqueue on torch's CURRENT stream: work queued on a side stream behind
     a long-running producer must see the producer's output."""
