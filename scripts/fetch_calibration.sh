@@ -15,7 +15,8 @@ f = glob.glob(out + "/**/*counter_collection.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == "FETCH_SIZE" and "calib" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Dispatch_Id"]))
 B, N = 1 << 18, 68
-known = {"calib_rows<16>": B * 2 * N * 4, "calib_rows<32>": B * 2 * N * 4, "calib_rows<24>": B * 3 * N * 4, "calib_wide": B * 2 * N * 4}
+known = {"calib_rows<16>": B * 2 * N * 4, "calib_rows<32>": B * 2 * N * 4, "calib_rows<24>": B * 3 * N * 4, "calib_wide": B * 2 * N * 4,
+         "calib_lines": B * 5 * N * 4}
 res = collections.OrderedDict()
 seen = collections.Counter()
 for r in rows:

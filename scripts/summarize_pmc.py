@@ -86,14 +86,17 @@ for label, kern, B, N, own in LAUNCHES:
         del s["fetch_bytes_2x"], s["fetch_2x_over_input"]
     if "qeif_moment_lines_kernel" in kern:
         # 16-byte pieces: pixel runs are whole 128-byte lines (counted at half, like any wide read),
-        # pattern runs are 192 bytes at multiples of 64, i.e. one 128-byte and one 64-byte request, and
-        # the calibration probe shows short requests counted at more than half (0.77 of the bytes for
-        # 64-byte runs).  2 x FETCH_SIZE therefore over-counts the pattern half of the input by up to
-        # a third; the figure is kept as an upper bound.
-        s["fetch_calibration"] = ("2 x FETCH_SIZE is an upper bound for this kernel: its 64-byte requests (a third of "
-                                  "the pattern bytes) are counted at more than half")
-        uv_b, xyz_b = B * 8 * N, B * 12 * N
-        s["fetch_2x_if_read_once_with_64B_requests_counted_in_full"] = round((uv_b + xyz_b * 4.0 / 3.0) / in_bytes, 4)
+        # pattern runs are 192 bytes at multiples of 64 bytes, i.e. one 128-byte and one 64-byte request,
+        # and short requests are counted at more than half.  scripts/probes/fetch_calibration.hip
+        # (calib_lines) reads uv and xyz once in exactly this shape: FETCH_SIZE bytes / true bytes
+        # = 0.6312.  Divided out, what is left is the kernel's re-read ratio.
+        ratio = s["FETCH_SIZE"] * 1024 / (0.6312 * in_bytes)
+        s["fetch_calibration"] = ("FETCH_SIZE calibrated on this access shape (scripts/probes/fetch_calibration.hip, "
+                                  "calib_lines): a single read of the inputs would count %.0f bytes" % (0.6312 * in_bytes))
+        s["read_bytes_over_input"] = round(ratio, 4)
+        s["fetch_bytes_calibrated"] = ratio * in_bytes
+        s["hbm_bytes_per_launch"] = s["fetch_bytes_calibrated"] + s["write_bytes"]
+        del s["fetch_bytes_2x"], s["fetch_2x_over_input"]
     if "SQ_ACTIVE_INST_VALU" in s and "GRBM_GUI_ACTIVE" in s:
         # SQ_* activity counters tick in quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs
         s["valu_busy_frac"] = round(4 * s["SQ_ACTIVE_INST_VALU"] / 1024 / (s["GRBM_GUI_ACTIVE"] / 8), 4)
