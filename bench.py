@@ -472,7 +472,13 @@ def main():
                     solves_per_s=round(B68 / ms * 1e3, 1), kernel_ms=round(ms, 4), mean_iterations=round(it68, 3),
                     bytes_per_solve=nbytes, achieved_GBps=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4),
                     form="moments" if lib.pnp_get_qeif_form(B68, 68) == pnp._lib.QEIF_FORM_MOMENTS else "points",
-                    valu_fp64_TFLOPs=round(B68 * qeif_moment_flops(68, it68) / (ms * 1e-3) / 1e12, 2))
+                    valu_fp64_TFLOPs=round(B68 * qeif_moment_flops(68, it68) / (ms * 1e-3) / 1e12, 2),
+                    roofline=dict(bound="hbm", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                                  frac=round(gbs / HBM_PEAK_GBS, 5),
+                                  traffic=traffic_of("qeif_n68_b256k_%s_bytes_per_launch"
+                                                     % ("shared_pattern" if tag == "shared_pattern" else "per_problem_xyz")),
+                                  kernel="pnp::qeif_moment_kernel<float,16,true>" if tag == "shared_pattern"
+                                  else "pnp::qeif_moment_lines_kernel<float>", kernel_ms=round(ms, 4), bytes_per_solve=nbytes))
             lib.pnp_set_qeif_form(pnp._lib.QEIF_FORM_POINTS)        # the point-by-point form, for comparison
             try:
                 ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv68, P68d, K, want_rpy=False), 10)
