@@ -460,6 +460,20 @@ int lane_reserve(PipeLane &ln, size_t pinned_bytes, size_t dev_bytes)
     return PNP_OK;
 }
 
+// True when p points into page-locked host memory the HIP runtime knows (hipHostMalloc, a
+// registered range, a pinned torch tensor): copies from and to it run at bus speed without the
+// staging copy that pageable memory needs.
+bool is_page_locked(const void *p)
+{
+    if (!p) return true;   // an output the caller does not want: nothing to copy
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
 // The chunked form of a host-pointer call (see kPipeLanes).  per_in / per_out: array elements per
 // problem that go in (uv, and xyz when every problem has its own) and come out.  The shared
 // pattern, if any, is already on the device at d_shared_xyz.  run(d, first, count, stream) solves
@@ -505,6 +519,11 @@ int pipelined_host_call(Staging &st, int dev, hipStream_t s, int64_t B, int32_t 
     HIP_TRY(hipEventRecord(st.entry, s));
     for (int l = 0; l < lanes; ++l) HIP_TRY(hipStreamWaitEvent(st.lane[l].stream, st.entry, 0));
 
+    // arrays in page-locked memory are copied from and to directly; then a lane has no host copy
+    // of its own to do and waits only once, at its end
+    const bool in_locked = is_page_locked(h.uv) && (!own_xyz || is_page_locked(h.xyz));
+    const bool out_locked = is_page_locked(h.R) && is_page_locked(h.t) && is_page_locked(h.res) && is_page_locked(h.rpy) &&
+                            is_page_locked(h.iters) && is_page_locked(h.pid);
     struct Outcome {
         int rc = PNP_OK;
         char msg[sizeof g_err] = "";
@@ -519,9 +538,17 @@ int pipelined_host_call(Staging &st, int dev, hipStream_t s, int64_t B, int32_t 
             for (int64_t k = l; k < nchunks; k += lanes) {
                 const int64_t first = k * chunk;
                 const size_t n = static_cast<size_t>(std::min<int64_t>(chunk, B - first));
-                std::memcpy(pin + lay.uv, h.uv + first * 2 * N, n * 2 * N * sizeof(T));
-                if (own_xyz) std::memcpy(pin + lay.xyz, h.xyz + first * 3 * N, n * 3 * N * sizeof(T));
-                HIP_TRY(hipMemcpyAsync(dv, pin, lay.in_end, hipMemcpyHostToDevice, ln.stream));
+                if (in_locked) {
+                    HIP_TRY(hipMemcpyAsync(dv + lay.uv, h.uv + first * 2 * N, n * 2 * N * sizeof(T), hipMemcpyHostToDevice,
+                                           ln.stream));
+                    if (own_xyz)
+                        HIP_TRY(hipMemcpyAsync(dv + lay.xyz, h.xyz + first * 3 * N, n * 3 * N * sizeof(T),
+                                               hipMemcpyHostToDevice, ln.stream));
+                } else {
+                    std::memcpy(pin + lay.uv, h.uv + first * 2 * N, n * 2 * N * sizeof(T));
+                    if (own_xyz) std::memcpy(pin + lay.xyz, h.xyz + first * 3 * N, n * 3 * N * sizeof(T));
+                    HIP_TRY(hipMemcpyAsync(dv, pin, lay.in_end, hipMemcpyHostToDevice, ln.stream));
+                }
                 SolveIO<T> d;
                 d.uv = reinterpret_cast<const T *>(dv + lay.uv);
                 d.xyz = own_xyz ? reinterpret_cast<const T *>(dv + lay.xyz) : d_shared_xyz;
@@ -533,6 +560,21 @@ int pipelined_host_call(Staging &st, int dev, hipStream_t s, int64_t B, int32_t 
                 d.pid = h.pid ? reinterpret_cast<int32_t *>(dv + lay.pid) : nullptr;
                 const int rc = run(d, static_cast<int64_t>(n), ln.stream);
                 if (rc) return rc;
+                if (out_locked) {
+                    auto back = [&](void *dst, size_t at, size_t bytes) {
+                        return hipMemcpyAsync(dst, dv + at, bytes, hipMemcpyDeviceToHost, ln.stream);
+                    };
+                    HIP_TRY(back(h.R + first * 9, lay.R, n * 9 * sizeof(T)));
+                    HIP_TRY(back(h.t + first * 3, lay.t, n * 3 * sizeof(T)));
+                    if (h.res) HIP_TRY(back(h.res + first, lay.res, n * sizeof(T)));
+                    if (h.rpy) HIP_TRY(back(h.rpy + first * 3, lay.rpy, n * 3 * sizeof(T)));
+                    if (h.iters) HIP_TRY(back(h.iters + first, lay.iters, n * sizeof(int32_t)));
+                    if (h.pid) HIP_TRY(back(h.pid + first, lay.pid, n * sizeof(int32_t)));
+                    // the stream orders the next chunk's copy into this lane's device slice behind these;
+                    // the page-locked buffer is reused by the next chunk's inputs only if they are pageable
+                    if (!in_locked) HIP_TRY(hipStreamSynchronize(ln.stream));
+                    continue;
+                }
                 HIP_TRY(hipMemcpyAsync(pin + lay.in_end, dv + lay.in_end, lay.end - lay.in_end, hipMemcpyDeviceToHost,
                                        ln.stream));
                 HIP_TRY(hipStreamSynchronize(ln.stream));

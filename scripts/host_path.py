@@ -51,6 +51,18 @@ for tag, xyz, stride, nbytes in (("c_abi_qeif_own_xyz", own, 18, 120 + 48 + 8), 
                                                        t.ctypes.data, res.ctypes.data, it.ctypes.data, None, 0, None)))
     report[tag] = dict(ms_per_call=round(s * 1e3, 3), solves_per_s=round(B / s, 1), pcie_GBps=round(B * nbytes / s / 1e9, 2))
     print(tag, report[tag], flush=True)
+# the same with every array in page-locked memory (pinned torch tensors): no staging copies
+def locked(a):
+    t = torch.empty(a.shape, dtype=torch.from_numpy(a).dtype, pin_memory=True)
+    t.copy_(torch.from_numpy(a))
+    return t
+uv_l, own_l, P6_l = locked(uv), locked(own), locked(P6)
+R_l, t_l, res_l, it_l = locked(R), locked(t), locked(res), locked(it)
+for tag, xyz_l, stride, nbytes in (("c_abi_qeif_own_xyz_page_locked", own_l, 18, 120 + 48 + 8), ("c_abi_qeif_shared_xyz_page_locked", P6_l, 0, 48 + 48 + 8)):
+    s = wall(lambda: _lib.check(lib.pnp_qeif_batch_f32(uv_l.data_ptr(), xyz_l.data_ptr(), stride, Kc, B, 6, None, R_l.data_ptr(),
+                                                       t_l.data_ptr(), res_l.data_ptr(), it_l.data_ptr(), None, 0, None)))
+    report[tag] = dict(ms_per_call=round(s * 1e3, 3), solves_per_s=round(B / s, 1), pcie_GBps=round(B * nbytes / s / 1e9, 2))
+    print(tag, report[tag], flush=True)
 small = uv[:1000]
 s = wall(lambda: pnp.solve_pnp_batch(small, P6, K), reps=200)
 report["qeif_1000_problems"] = dict(us_per_call=round(s * 1e6, 1))

@@ -415,6 +415,35 @@ def test_large_host_pointer_calls_agree_with_the_device_path(torch_dev):
     assert all(np.array_equal(d64[k], h64[k]) for k in d64)
 
 
+def test_page_locked_host_arrays_are_copied_directly(torch_dev):
+    """Host arrays in page-locked memory (here: pinned torch tensors seen as NumPy arrays) skip the
+    staging copy of the chunked host path, on the way in, on the way out, or both; the results
+    are those of the device-pointer path whichever side is page-locked."""
+    import torch
+    from pnp_solver_test_amd import synth
+    lib = _lib.load()
+    B = 260_003
+    uv, _ = synth.stress_batch(B, seed=12, pattern=synth.PATTERN6, K=K, is_quantized=True)
+    own = np.ascontiguousarray(np.broadcast_to(P6f, (B, 6, 3))) + np.float32(1e-4) * (np.arange(B, dtype=np.float32) % 5)[:, None, None]
+    want = solve_dev(uv, own, torch_dev)
+
+    def locked(a):
+        t = torch.empty(a.shape, dtype=torch.from_numpy(a).dtype, pin_memory=True)
+        t.copy_(torch.from_numpy(a))
+        return t
+
+    for pin_in, pin_out in ((True, True), (True, False), (False, True)):
+        keep = []
+        u, x = (locked(uv), locked(own)) if pin_in else (torch.from_numpy(uv), torch.from_numpy(own))
+        mk = (lambda shape, dt: torch.full(shape, -7, dtype=dt, pin_memory=True)) if pin_out else (lambda shape, dt: torch.full(shape, -7, dtype=dt))
+        R, t, res, it = mk((B, 9), torch.float32), mk((B, 3), torch.float32), mk((B,), torch.float32), mk((B,), torch.int32)
+        keep += [u, x, R, t, res, it]
+        _lib.check(lib.pnp_qeif_batch_f32(u.data_ptr(), x.data_ptr(), 18, _lib.k_array(K), B, 6, None, R.data_ptr(),
+                                          t.data_ptr(), res.data_ptr(), it.data_ptr(), None, _lib.PTR_HOST, None))
+        assert np.array_equal(R.numpy().reshape(B, 3, 3), want["R"]) and np.array_equal(t.numpy(), want["t"]), (pin_in, pin_out)
+        assert np.array_equal(res.numpy(), want["res_norm"]) and np.array_equal(it.numpy(), want["iters"]), (pin_in, pin_out)
+
+
 @pytest.mark.parametrize("B", [1, 2, 63, 64, 255, 256, 257, 1000])
 def test_ragged_batches(golden, torch_dev, B):
     g, uv = stress_uv6(golden)
