@@ -513,6 +513,22 @@ def main():
                 solves_per_s=round(B / hs, 1), ms_per_call=round(hs * 1e3, 3),
                 pcie_GBps=round(B * (bytes_per_solve + 8) / hs / 1e9, 2),
                 what="NumPy arrays in, NumPy arrays out: chunks through page-locked buffers on 4 host threads and streams")
+            # ... and as host tensors in page-locked memory: the kernels work on them over the bus
+            uv_p, xyz_p = torch.from_numpy(uv_h).pin_memory(), torch.from_numpy(xyz_h).pin_memory()
+
+            def pinned_call():
+                return pnp.solve_pnp_batch(uv_p, xyz_p, K, want_rpy=False)
+            pinned_call()
+            pinned_call()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                pinned_call()
+            hs = (time.perf_counter() - t0) / 5
+            other["qeif_n6_b1m_page_locked_host_tensors_pcie_inclusive"] = dict(
+                solves_per_s=round(B / hs, 1), ms_per_call=round(hs * 1e3, 3),
+                pcie_GBps=round(B * (bytes_per_solve + 8) / hs / 1e9, 2),
+                what="pinned host tensors in, pinned host tensors out: one launch that reads and writes host memory")
+            del uv_p, xyz_p
             line["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:   # last: the GPU idles (and clocks down) meanwhile
             line["cpu_baseline"] = cpu_baseline(uv_h, xyz_h, K)

@@ -33,6 +33,10 @@
  *     page-locked buffers and streams of the library's own, so that the copy from the caller's
  *     pageable arrays, the transfers in both directions and the kernels overlap.  Results are
  *     those of one launch over the whole batch; work already queued on hip_stream is waited for.
+ *   - A host-pointer call all of whose arrays are page-locked, mapped host memory (hipHostMalloc
+ *     and the like) is launched on that memory itself: the kernels read and write it over the
+ *     bus, nothing is staged or copied.  With only the inputs or only the outputs page-locked,
+ *     that side of the chunked path skips its staging copy.
  */
 #ifndef PNP_HIP_H
 #define PNP_HIP_H

@@ -82,7 +82,8 @@ def solve_pnp_batch(uv, xyz, K, *, method="qeif", params=None, num_it=None, want
 
     Returns a dict: R (B,3,3), t (B,3), t3 (B,), res_norm (B,), rpy_deg (B,3) = roll, yaw, pitch
     in the reference's tuple order (if want_rpy), iters (B,) int32 (QEIF only).  Arrays are of
-    the same kind (NumPy / torch on the same device) as `uv`.
+    the same kind as `uv`: NumPy, torch on the same device, or - for a host tensor in pinned
+    memory - pinned host tensors (no copies then: the kernels work on that memory over the bus).
     """
     if method not in METHODS:
         raise ValueError("method must be one of %s" % (METHODS,))
@@ -136,12 +137,19 @@ def _solve_torch(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, f
     import torch
     tt = torch.float64 if ft == np.dtype(np.float64) else torch.float32
 
-    if not uv.is_cuda:
-        raise ValueError("torch inputs must live on a HIP device (got %s); pass NumPy arrays for "
-                         "host memory" % uv.device)
+    # Tensors on a HIP device, or host tensors in page-locked memory (pin_memory=True): the latter
+    # go in as host pointers, the results come back as pinned host tensors, and with every array
+    # page-locked the kernels work on that memory over the bus, without copies.
+    on_host = not uv.is_cuda
+    if on_host and not uv.is_pinned():
+        raise ValueError("torch inputs must live on a HIP device or in pinned host memory (got an unpinned "
+                         "%s tensor); pass NumPy arrays for pageable host memory" % uv.device)
     src = patterns if patterns is not None else xyz
     if not _is_torch(src):
-        src = torch.as_tensor(np.ascontiguousarray(src, dtype=ft), device=uv.device)
+        src = torch.as_tensor(np.ascontiguousarray(src, dtype=ft))
+        src = src.pin_memory() if on_host else src.to(uv.device)
+    elif on_host and not (src.device.type == "cpu" and src.is_pinned()):
+        raise ValueError("with uv in pinned host memory, xyz must be a pinned host tensor or a NumPy array")
     if uv.dtype != tt or src.dtype != tt:
         raise TypeError("uv and xyz must both be %s tensors (got %s and %s)" % (tt, uv.dtype, src.dtype))
     if src.device != uv.device:
@@ -155,22 +163,22 @@ def _solve_torch(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, f
     else:
         B, N, stride, n_pat = _shapes(tuple(uv.shape), tuple(src.shape))
     dev = uv.device
-    with torch.cuda.device(dev):
-        out = dict(R=torch.empty((B, 3, 3), dtype=tt, device=dev),
-                   t=torch.empty((B, 3), dtype=tt, device=dev))
+    where = dict(pin_memory=True) if on_host else dict(device=dev)
+    with (torch.cuda.device(torch.cuda.current_device()) if on_host else torch.cuda.device(dev)):
+        out = dict(R=torch.empty((B, 3, 3), dtype=tt, **where), t=torch.empty((B, 3), dtype=tt, **where))
         if want_res:
-            out["res_norm"] = torch.empty(B, dtype=tt, device=dev)
-        rpy = torch.empty((B, 3), dtype=tt, device=dev) if want_rpy else None
-        iters = torch.empty(B, dtype=torch.int32, device=dev) if method == "qeif" else None
-        pid = torch.empty(B, dtype=torch.int32, device=dev) if patterns is not None else None
-        stream = torch.cuda.current_stream(dev).cuda_stream
+            out["res_norm"] = torch.empty(B, dtype=tt, **where)
+        rpy = torch.empty((B, 3), dtype=tt, **where) if want_rpy else None
+        iters = torch.empty(B, dtype=torch.int32, **where) if method == "qeif" else None
+        pid = torch.empty(B, dtype=torch.int32, **where) if patterns is not None else None
+        stream = torch.cuda.current_stream().cuda_stream
 
         def ptr(a):
             return None if a is None else a.data_ptr()
 
         _call(lib, method, ptr(uv), ptr(src), stride, n_pat, Kc, B, N, params, num_it, ptr(out["R"]),
-              ptr(out["t"]), ptr(out.get("res_norm")), ptr(iters), ptr(rpy), ptr(pid), _lib.PTR_DEVICE,
-              stream, patterns is not None, ft)
+              ptr(out["t"]), ptr(out.get("res_norm")), ptr(iters), ptr(rpy), ptr(pid),
+              _lib.PTR_HOST if on_host else _lib.PTR_DEVICE, stream, patterns is not None, ft)
     out["t3"] = out["t"][:, 2]
     if rpy is not None:
         out["rpy_deg"] = rpy

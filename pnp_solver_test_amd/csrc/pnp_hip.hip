@@ -474,6 +474,33 @@ bool is_page_locked(const void *p)
     return a.type == hipMemoryTypeHost;
 }
 
+// Device addresses of a call's host arrays when every one of them is page-locked and mapped;
+// false (d unspecified) otherwise.
+template <typename T>
+bool map_page_locked(const SolveIO<T> &h, SolveIO<T> &d)
+{
+    const void *all[] = {h.uv, h.xyz, h.R, h.t, h.res, h.rpy, h.iters, h.pid};
+    void *mapped[8];
+    for (int i = 0; i < 8; ++i) {
+        mapped[i] = nullptr;
+        if (!all[i]) continue;
+        if (!is_page_locked(all[i])) return false;
+        if (hipHostGetDevicePointer(&mapped[i], const_cast<void *>(all[i]), 0) != hipSuccess || !mapped[i]) {
+            (void)hipGetLastError();
+            return false;
+        }
+    }
+    d.uv = static_cast<const T *>(mapped[0]);
+    d.xyz = static_cast<const T *>(mapped[1]);
+    d.R = static_cast<T *>(mapped[2]);
+    d.t = static_cast<T *>(mapped[3]);
+    d.res = static_cast<T *>(mapped[4]);
+    d.rpy = static_cast<T *>(mapped[5]);
+    d.iters = static_cast<int32_t *>(mapped[6]);
+    d.pid = static_cast<int32_t *>(mapped[7]);
+    return true;
+}
+
 // The chunked form of a host-pointer call (see kPipeLanes).  per_in / per_out: array elements per
 // problem that go in (uv, and xyz when every problem has its own) and come out.  The shared
 // pattern, if any, is already on the device at d_shared_xyz.  run(d, first, count, stream) solves
@@ -621,9 +648,19 @@ int with_host_staging(hipStream_t s, int64_t B, int32_t N, size_t xyz_elems, boo
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= kMaxDevices) return fail(PNP_E_HIP, "device index %d out of range", dev);
+    const size_t nB = static_cast<size_t>(B);
+    // Every array page-locked: the kernels read and write the caller's memory over the bus (the
+    // device addresses of the host arrays), one launch, no staging and no copies.  1M six-point
+    // problems: 2.4 ms against 4.2 ms through the chunked copies.
+    {
+        SolveIO<T> d;
+        if (map_page_locked(h, d)) {
+            SyncOnExit guard(s);
+            return run(d, B, s);
+        }
+    }
     Staging &st = g_staging[dev];
     std::lock_guard<std::mutex> lock(st.mu);
-    const size_t nB = static_cast<size_t>(B);
     if ((nB * 2 * N + (own_xyz ? xyz_elems : 0) + nB * 12) * sizeof(T) >= kPipeMinBytes) {
         const T *d_shared = nullptr;
         if (!own_xyz) {   // the shared pattern(s) go up once, ahead of the lanes

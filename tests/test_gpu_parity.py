@@ -416,9 +416,11 @@ def test_large_host_pointer_calls_agree_with_the_device_path(torch_dev):
 
 
 def test_page_locked_host_arrays_are_copied_directly(torch_dev):
-    """Host arrays in page-locked memory (here: pinned torch tensors seen as NumPy arrays) skip the
-    staging copy of the chunked host path, on the way in, on the way out, or both; the results
-    are those of the device-pointer path whichever side is page-locked."""
+    """Host arrays in page-locked memory (here: pinned torch tensors): with every array page-locked
+    the kernels work on the caller's memory over the bus (one launch, no copies), with only the
+    inputs or only the outputs page-locked that side skips the staging copy of the chunked path;
+    the results are those of the device-pointer path in every case, for a large and a small call
+    and for the DLT entry point."""
     import torch
     from pnp_solver_test_amd import synth
     lib = _lib.load()
@@ -442,6 +444,37 @@ def test_page_locked_host_arrays_are_copied_directly(torch_dev):
                                           t.data_ptr(), res.data_ptr(), it.data_ptr(), None, _lib.PTR_HOST, None))
         assert np.array_equal(R.numpy().reshape(B, 3, 3), want["R"]) and np.array_equal(t.numpy(), want["t"]), (pin_in, pin_out)
         assert np.array_equal(res.numpy(), want["res_norm"]) and np.array_equal(it.numpy(), want["iters"]), (pin_in, pin_out)
+        if pin_in and pin_out:
+            R.fill_(-7), t.fill_(-7)
+            _lib.check(lib.pnp_qeif_batch_f32(u.data_ptr(), x.data_ptr(), 18, _lib.k_array(K), 1000, 6, None, R.data_ptr(),
+                                              t.data_ptr(), None, None, None, _lib.PTR_HOST, None))
+            assert np.array_equal(R.numpy()[:1000].reshape(1000, 3, 3), want["R"][:1000]) and np.all(R.numpy()[1000:] == -7)
+            wd = solve_dev(uv, own, torch_dev, method="dlt")
+            _lib.check(lib.pnp_dlt_batch_f32(u.data_ptr(), x.data_ptr(), 18, _lib.k_array(K), B, 6, 3, R.data_ptr(),
+                                             t.data_ptr(), res.data_ptr(), None, _lib.PTR_HOST, None))
+            assert np.array_equal(R.numpy().reshape(B, 3, 3), wd["R"], equal_nan=True)
+            assert np.array_equal(res.numpy(), wd["res_norm"], equal_nan=True)
+
+
+def test_pinned_host_tensors_in_pinned_host_tensors_out(golden, torch_dev):
+    """solve_pnp_batch on host tensors in pinned memory: results are pinned host tensors equal to
+    the device path's (QEIF with a pattern per problem, a shared one, two patterns, DLT); an
+    unpinned host tensor is refused (NumPy arrays are the interface for pageable memory)."""
+    import torch
+    g, uv = stress_uv6(golden)
+    own = np.ascontiguousarray(np.broadcast_to(P6f, (len(uv), 6, 3)))
+    pats = np.stack([P6f, po.pattern_array(po.PATTERN_HOLLY, po.LM6_KEYS).astype(np.float32)])
+    uv_p, own_p = torch.from_numpy(uv).pin_memory(), torch.from_numpy(own).pin_memory()
+    for kw, xyz_h, xyz_np in ((dict(), own_p, own), (dict(), P6f, P6f), (dict(method="dlt"), own_p, own),
+                              (dict(patterns=pats), None, None)):
+        got = pnp.solve_pnp_batch(uv_p, xyz_h, K, **kw)
+        want = solve_dev(uv, xyz_np, torch_dev, **kw)
+        assert set(got) == set(want)
+        for k in want:
+            assert got[k].device.type == "cpu" and (k == "t3" or got[k].is_pinned()), k
+            assert np.array_equal(got[k].numpy(), want[k], equal_nan=True), (sorted(kw), k)
+    with pytest.raises(ValueError):
+        pnp.solve_pnp_batch(torch.from_numpy(uv), P6f, K)
 
 
 @pytest.mark.parametrize("B", [1, 2, 63, 64, 255, 256, 257, 1000])
