@@ -512,7 +512,7 @@ def main():
             other["qeif_n6_b1m_host_pointers_pcie_inclusive"] = dict(
                 solves_per_s=round(B / hs, 1), ms_per_call=round(hs * 1e3, 3),
                 pcie_GBps=round(B * (bytes_per_solve + 8) / hs / 1e9, 2),
-                what="NumPy arrays in, NumPy arrays out: chunks through page-locked buffers on 4 host threads and streams")
+                what="NumPy arrays in, NumPy arrays out: chunks through page-locked buffers on 8 host threads, kernels launched on those buffers")
             # ... and as host tensors in page-locked memory: the kernels work on them over the bus
             uv_p, xyz_p = torch.from_numpy(uv_h).pin_memory(), torch.from_numpy(xyz_h).pin_memory()
 

@@ -28,15 +28,15 @@
  *   - Output pointers documented as optional may be NULL.
  *   - Thread safety: calls are independent as long as they do not share output buffers;
  *     host-pointer calls on one device serialise on that device's staging buffers.
- *   - Host-pointer calls that move 16 MB or more are cut into chunks of about 8 MB which four
- *     host threads (three started by the call, joined before it returns) carry through
- *     page-locked buffers and streams of the library's own, so that the copy from the caller's
- *     pageable arrays, the transfers in both directions and the kernels overlap.  Results are
- *     those of one launch over the whole batch; work already queued on hip_stream is waited for.
- *   - A host-pointer call all of whose arrays are page-locked, mapped host memory (hipHostMalloc
- *     and the like) is launched on that memory itself: the kernels read and write it over the
- *     bus, nothing is staged or copied.  With only the inputs or only the outputs page-locked,
- *     that side of the chunked path skips its staging copy.
+ *   - Host-pointer calls never copy to device memory when they can help it: the kernels are
+ *     launched on host memory and read and write it over the bus.  A call all of whose arrays
+ *     are page-locked, mapped host memory (hipHostMalloc and the like) is one launch on those
+ *     arrays.  Otherwise calls that move 16 MB or more are cut into chunks of about 4 MB which
+ *     eight host threads (seven started by the call, joined before it returns) carry through
+ *     page-locked buffers and streams of the library's own: copy a chunk of the pageable arrays
+ *     in, launch on the buffer, copy the results out, the lanes overlapping each other; a side
+ *     (inputs, outputs) that is page-locked is used as it is.  Results are those of one launch
+ *     over the whole batch; work already queued on hip_stream is waited for.
  */
 #ifndef PNP_HIP_H
 #define PNP_HIP_H

@@ -65,18 +65,22 @@ constexpr int64_t kMomentMinBatch = 2048;
 
 // ---- per-device staging for host-pointer calls -------------------------------------------
 
-// Large host-pointer calls are cut into chunks that kPipeLanes host threads carry through the
-// device side by side, each with a stream, a page-locked buffer and a slice of device memory of
-// its own: while one lane copies a chunk from the caller's (pageable) arrays into its page-locked
-// buffer, another's chunk is on the bus, a third's is being solved and a fourth's results are on
-// their way back.  Measured on the pool's hosts: one thread copies pageable -> page-locked memory
-// at 23 GB/s, eight at 80 GB/s; page-locked memory crosses the bus at 57 GB/s in either direction,
-// both at once; pageable memory at 29 GB/s in and 18 GB/s out, one direction at a time.
+// Large host-pointer calls are cut into chunks that kPipeLanes host threads carry side by side,
+// each with a stream and a page-locked buffer of its own.  A lane copies a chunk from the caller's
+// (pageable) arrays into its buffer, launches the solver on the device address of that buffer -
+// the kernels read the inputs and write the results over the bus, there are no copy operations and
+// no device-side staging - waits, and copies the results out to the caller's arrays; a side of the
+// call (inputs, outputs) whose arrays are page-locked already is handed to the kernels as it is.
+// Measured on the pool's hosts: one thread copies pageable -> page-locked memory at 23 GB/s, eight
+// at 80 GB/s; page-locked memory crosses the bus at 57 GB/s in either direction, both at once.
+// 1M six-point problems with a pattern each: 3.5-3.8 ms with 8 lanes and 4 MB chunks, against 4.5
+// ms with four lanes that copied each chunk to device memory and back (2 + 6 copy operations per
+// chunk), 10.6 ms without chunks.
 #ifndef PNP_PIPE_LANES
-#define PNP_PIPE_LANES 4
+#define PNP_PIPE_LANES 8
 #endif
 #ifndef PNP_PIPE_CHUNK_MB
-#define PNP_PIPE_CHUNK_MB 8
+#define PNP_PIPE_CHUNK_MB 4
 #endif
 constexpr int kPipeLanes = PNP_PIPE_LANES;
 constexpr size_t kPipeChunkBytes = size_t(PNP_PIPE_CHUNK_MB) << 20;   // input bytes per chunk, about
@@ -84,8 +88,8 @@ constexpr size_t kPipeMinBytes = size_t(16) << 20;    // calls moving less than 
 
 struct PipeLane {
     hipStream_t stream = nullptr;
-    void *pinned = nullptr, *dev = nullptr;
-    size_t pinned_cap = 0, dev_cap = 0;
+    void *pinned = nullptr;
+    size_t pinned_cap = 0;
 };
 
 struct Staging {
@@ -440,7 +444,7 @@ struct SolveIO {
 };
 
 // Grow-only resources of one pipeline lane of the current device; caller holds the staging lock.
-int lane_reserve(PipeLane &ln, size_t pinned_bytes, size_t dev_bytes)
+int lane_reserve(PipeLane &ln, size_t pinned_bytes)
 {
     if (!ln.stream) HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
     if (pinned_bytes > ln.pinned_cap) {
@@ -450,19 +454,11 @@ int lane_reserve(PipeLane &ln, size_t pinned_bytes, size_t dev_bytes)
         HIP_TRY(hipHostMalloc(&ln.pinned, pinned_bytes, hipHostMallocDefault));
         ln.pinned_cap = pinned_bytes;
     }
-    if (dev_bytes > ln.dev_cap) {
-        if (ln.dev) HIP_TRY(hipFree(ln.dev));
-        ln.dev = nullptr;
-        ln.dev_cap = 0;
-        HIP_TRY(hipMalloc(&ln.dev, dev_bytes));
-        ln.dev_cap = dev_bytes;
-    }
     return PNP_OK;
 }
 
 // True when p points into page-locked host memory the HIP runtime knows (hipHostMalloc, a
-// registered range, a pinned torch tensor): copies from and to it run at bus speed without the
-// staging copy that pageable memory needs.
+// registered range, a pinned torch tensor): memory the kernels can work on over the bus.
 bool is_page_locked(const void *p)
 {
     if (!p) return true;   // an output the caller does not want: nothing to copy
@@ -514,7 +510,7 @@ int pipelined_host_call(Staging &st, int dev, hipStream_t s, int64_t B, int32_t 
     chunk = std::max<int64_t>(1024, chunk & ~int64_t(255));
     const int64_t nchunks = (B + chunk - 1) / chunk;
     const int lanes = static_cast<int>(std::min<int64_t>(kPipeLanes, nchunks));
-    // one layout for the page-locked buffer and the device slice of a lane
+    // layout of a lane's page-locked buffer
     struct Layout {
         size_t uv, xyz, R, t, res, rpy, iters, pid, in_end, end;
     } lay;
@@ -538,7 +534,7 @@ int pipelined_host_call(Staging &st, int dev, hipStream_t s, int64_t B, int32_t 
         lay.end = off;
     }
     for (int l = 0; l < lanes; ++l) {
-        const int rc = lane_reserve(st.lane[l], lay.end, lay.end);
+        const int rc = lane_reserve(st.lane[l], lay.end);
         if (rc) return rc;
     }
     // the lanes' streams start after whatever the caller's stream holds at this point
@@ -546,11 +542,33 @@ int pipelined_host_call(Staging &st, int dev, hipStream_t s, int64_t B, int32_t 
     HIP_TRY(hipEventRecord(st.entry, s));
     for (int l = 0; l < lanes; ++l) HIP_TRY(hipStreamWaitEvent(st.lane[l].stream, st.entry, 0));
 
-    // arrays in page-locked memory are copied from and to directly; then a lane has no host copy
-    // of its own to do and waits only once, at its end
-    const bool in_locked = is_page_locked(h.uv) && (!own_xyz || is_page_locked(h.xyz));
-    const bool out_locked = is_page_locked(h.R) && is_page_locked(h.t) && is_page_locked(h.res) && is_page_locked(h.rpy) &&
-                            is_page_locked(h.iters) && is_page_locked(h.pid);
+    // a side of the call whose arrays are all page-locked is given to the kernels as it is
+    SolveIO<T> m{};   // device addresses of the caller's page-locked arrays
+    auto map_side = [&](std::initializer_list<std::pair<const void *, void **>> arrays) {
+        for (auto &a : arrays) {
+            *a.second = nullptr;
+            if (!a.first) continue;
+            if (!is_page_locked(a.first) || hipHostGetDevicePointer(a.second, const_cast<void *>(a.first), 0) != hipSuccess ||
+                !*a.second) {
+                (void)hipGetLastError();
+                return false;
+            }
+        }
+        return true;
+    };
+    void *q_uv, *q_xyz, *q_R, *q_t, *q_res, *q_rpy, *q_iters, *q_pid;
+    const bool in_locked = map_side({{h.uv, &q_uv}, {own_xyz ? h.xyz : nullptr, &q_xyz}});
+    const bool out_locked = map_side({{h.R, &q_R}, {h.t, &q_t}, {h.res, &q_res}, {h.rpy, &q_rpy}, {h.iters, &q_iters},
+                                      {h.pid, &q_pid}});
+    m.uv = static_cast<const T *>(q_uv);
+    m.xyz = static_cast<const T *>(q_xyz);
+    m.R = static_cast<T *>(q_R);
+    m.t = static_cast<T *>(q_t);
+    m.res = static_cast<T *>(q_res);
+    m.rpy = static_cast<T *>(q_rpy);
+    m.iters = static_cast<int32_t *>(q_iters);
+    m.pid = static_cast<int32_t *>(q_pid);
+
     struct Outcome {
         int rc = PNP_OK;
         char msg[sizeof g_err] = "";
@@ -561,50 +579,43 @@ int pipelined_host_call(Staging &st, int dev, hipStream_t s, int64_t B, int32_t 
         PipeLane &ln = st.lane[l];
         auto body = [&]() -> int {
             HIP_TRY(hipSetDevice(dev));
-            char *pin = static_cast<char *>(ln.pinned), *dv = static_cast<char *>(ln.dev);
+            char *pin = static_cast<char *>(ln.pinned);
+            void *mapped = nullptr;
+            HIP_TRY(hipHostGetDevicePointer(&mapped, pin, 0));
+            char *mp = static_cast<char *>(mapped);   // the lane's buffer as the device sees it
             for (int64_t k = l; k < nchunks; k += lanes) {
                 const int64_t first = k * chunk;
                 const size_t n = static_cast<size_t>(std::min<int64_t>(chunk, B - first));
+                SolveIO<T> d;
                 if (in_locked) {
-                    HIP_TRY(hipMemcpyAsync(dv + lay.uv, h.uv + first * 2 * N, n * 2 * N * sizeof(T), hipMemcpyHostToDevice,
-                                           ln.stream));
-                    if (own_xyz)
-                        HIP_TRY(hipMemcpyAsync(dv + lay.xyz, h.xyz + first * 3 * N, n * 3 * N * sizeof(T),
-                                               hipMemcpyHostToDevice, ln.stream));
+                    d.uv = m.uv + first * 2 * N;
+                    d.xyz = own_xyz ? m.xyz + first * 3 * N : d_shared_xyz;
                 } else {
                     std::memcpy(pin + lay.uv, h.uv + first * 2 * N, n * 2 * N * sizeof(T));
                     if (own_xyz) std::memcpy(pin + lay.xyz, h.xyz + first * 3 * N, n * 3 * N * sizeof(T));
-                    HIP_TRY(hipMemcpyAsync(dv, pin, lay.in_end, hipMemcpyHostToDevice, ln.stream));
+                    d.uv = reinterpret_cast<const T *>(mp + lay.uv);
+                    d.xyz = own_xyz ? reinterpret_cast<const T *>(mp + lay.xyz) : d_shared_xyz;
                 }
-                SolveIO<T> d;
-                d.uv = reinterpret_cast<const T *>(dv + lay.uv);
-                d.xyz = own_xyz ? reinterpret_cast<const T *>(dv + lay.xyz) : d_shared_xyz;
-                d.R = reinterpret_cast<T *>(dv + lay.R);
-                d.t = reinterpret_cast<T *>(dv + lay.t);
-                d.res = h.res ? reinterpret_cast<T *>(dv + lay.res) : nullptr;
-                d.rpy = h.rpy ? reinterpret_cast<T *>(dv + lay.rpy) : nullptr;
-                d.iters = h.iters ? reinterpret_cast<int32_t *>(dv + lay.iters) : nullptr;
-                d.pid = h.pid ? reinterpret_cast<int32_t *>(dv + lay.pid) : nullptr;
+                if (out_locked) {
+                    d.R = m.R + first * 9;
+                    d.t = m.t + first * 3;
+                    d.res = h.res ? m.res + first : nullptr;
+                    d.rpy = h.rpy ? m.rpy + first * 3 : nullptr;
+                    d.iters = h.iters ? m.iters + first : nullptr;
+                    d.pid = h.pid ? m.pid + first : nullptr;
+                } else {
+                    d.R = reinterpret_cast<T *>(mp + lay.R);
+                    d.t = reinterpret_cast<T *>(mp + lay.t);
+                    d.res = h.res ? reinterpret_cast<T *>(mp + lay.res) : nullptr;
+                    d.rpy = h.rpy ? reinterpret_cast<T *>(mp + lay.rpy) : nullptr;
+                    d.iters = h.iters ? reinterpret_cast<int32_t *>(mp + lay.iters) : nullptr;
+                    d.pid = h.pid ? reinterpret_cast<int32_t *>(mp + lay.pid) : nullptr;
+                }
                 const int rc = run(d, static_cast<int64_t>(n), ln.stream);
                 if (rc) return rc;
-                if (out_locked) {
-                    auto back = [&](void *dst, size_t at, size_t bytes) {
-                        return hipMemcpyAsync(dst, dv + at, bytes, hipMemcpyDeviceToHost, ln.stream);
-                    };
-                    HIP_TRY(back(h.R + first * 9, lay.R, n * 9 * sizeof(T)));
-                    HIP_TRY(back(h.t + first * 3, lay.t, n * 3 * sizeof(T)));
-                    if (h.res) HIP_TRY(back(h.res + first, lay.res, n * sizeof(T)));
-                    if (h.rpy) HIP_TRY(back(h.rpy + first * 3, lay.rpy, n * 3 * sizeof(T)));
-                    if (h.iters) HIP_TRY(back(h.iters + first, lay.iters, n * sizeof(int32_t)));
-                    if (h.pid) HIP_TRY(back(h.pid + first, lay.pid, n * sizeof(int32_t)));
-                    // the stream orders the next chunk's copy into this lane's device slice behind these;
-                    // the page-locked buffer is reused by the next chunk's inputs only if they are pageable
-                    if (!in_locked) HIP_TRY(hipStreamSynchronize(ln.stream));
-                    continue;
-                }
-                HIP_TRY(hipMemcpyAsync(pin + lay.in_end, dv + lay.in_end, lay.end - lay.in_end, hipMemcpyDeviceToHost,
-                                       ln.stream));
+                // the lane's buffer is reused by its next chunk, and read below
                 HIP_TRY(hipStreamSynchronize(ln.stream));
+                if (out_locked) continue;
                 std::memcpy(h.R + first * 9, pin + lay.R, n * 9 * sizeof(T));
                 std::memcpy(h.t + first * 3, pin + lay.t, n * 3 * sizeof(T));
                 if (h.res) std::memcpy(h.res + first, pin + lay.res, n * sizeof(T));
