@@ -96,13 +96,14 @@ struct Staging {
     std::mutex mu;
     void *buf = nullptr;
     size_t cap = 0;
-    void *pinned = nullptr;  // kSmallCall bytes of page-locked host memory, mirror of buf's first bytes
+    void *pinned = nullptr;  // page-locked host memory for calls below the chunking threshold (grow-only)
+    void *pinned_dev = nullptr;  // its device address
+    size_t pinned_cap = 0;
     PipeLane lane[kPipeLanes];
     hipEvent_t entry = nullptr;  // marks the caller's stream at the start of a pipelined call
 };
 
-// Host-pointer calls whose arrays fit this many bytes go through the pinned mirror: one copy in
-// and one copy out instead of one per array (each copy from pageable memory costs ~10 us).
+// Smallest size of the page-locked buffer that calls below the chunking threshold go through.
 constexpr size_t kSmallCall = 256 * 1024;
 Staging g_staging[kMaxDevices];
 
@@ -649,9 +650,10 @@ int pipelined_host_call(Staging &st, int dev, hipStream_t s, int64_t B, int32_t 
     return PNP_OK;
 }
 
-// Copies the inputs of a host-pointer call to the device, runs `run` on device pointers and
-// copies the requested outputs back.  Synchronises the stream before returning.
-// run(d, count, stream) solves `count` problems from the device arrays d on `stream`.
+// A host-pointer call: `run` is launched on page-locked host memory (the caller's arrays if they
+// are, buffers of the library's own that the arrays are copied through otherwise), which the
+// kernels read and write over the bus.  Synchronises the stream before returning.
+// run(d, count, stream) solves `count` problems from the arrays d (device addresses) on `stream`.
 template <typename T, typename Run>
 int with_host_staging(hipStream_t s, int64_t B, int32_t N, size_t xyz_elems, bool own_xyz, const SolveIO<T> &h,
                       Run run)
@@ -683,59 +685,50 @@ int with_host_staging(hipStream_t s, int64_t B, int32_t N, size_t xyz_elems, boo
         }
         return pipelined_host_call<T>(st, dev, s, B, N, own_xyz, d_shared, h, run);
     }
+    // Smaller calls: one page-locked buffer holds inputs and results, the kernels work on it over
+    // the bus (no device staging, no copy operations), the caller's stream carries the launch.
     const size_t total = 256 * 10 + (nB * 2 * N + xyz_elems + nB * (9 + 3 + 1 + 3)) * sizeof(T) +
                          2 * nB * sizeof(int32_t);
-    int rc = staging_reserve(st, total);
-    if (rc) return rc;
-    Carver c(st.buf);
-    SolveIO<T> d;
-    T *d_uv = c.take<T>(nB * 2 * N);
-    T *d_xyz = c.take<T>(xyz_elems);
-    const size_t in_bytes = c.off;
-    d.uv = d_uv;
-    d.xyz = d_xyz;
-    d.R = c.take<T>(nB * 9);
-    d.t = c.take<T>(nB * 3);
-    d.res = h.res ? c.take<T>(nB) : nullptr;
-    d.rpy = h.rpy ? c.take<T>(nB * 3) : nullptr;
-    d.iters = h.iters ? c.take<int32_t>(nB) : nullptr;
-    d.pid = h.pid ? c.take<int32_t>(nB) : nullptr;
-    const size_t all_bytes = c.off;
-    SyncOnExit guard(s);   // every exit below, error or not, leaves no copy in flight
-
-    if (all_bytes <= kSmallCall) {
-        // small call: gather the inputs in the pinned mirror, one copy each way
-        if (!st.pinned) HIP_TRY(hipHostMalloc(&st.pinned, kSmallCall, hipHostMallocDefault));
-        char *m = static_cast<char *>(st.pinned);
-        auto mirror = [&](const void *dev_ptr) { return m + (static_cast<const char *>(dev_ptr) - static_cast<char *>(st.buf)); };
-        std::memcpy(mirror(d_uv), h.uv, nB * 2 * N * sizeof(T));
-        std::memcpy(mirror(d_xyz), h.xyz, xyz_elems * sizeof(T));
-        HIP_TRY(hipMemcpyAsync(st.buf, m, in_bytes, hipMemcpyHostToDevice, s));
-        rc = run(d, B, s);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(m + in_bytes, static_cast<char *>(st.buf) + in_bytes, all_bytes - in_bytes,
-                               hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        std::memcpy(h.R, mirror(d.R), nB * 9 * sizeof(T));
-        std::memcpy(h.t, mirror(d.t), nB * 3 * sizeof(T));
-        if (h.res) std::memcpy(h.res, mirror(d.res), nB * sizeof(T));
-        if (h.rpy) std::memcpy(h.rpy, mirror(d.rpy), nB * 3 * sizeof(T));
-        if (h.iters) std::memcpy(h.iters, mirror(d.iters), nB * sizeof(int32_t));
-        if (h.pid) std::memcpy(h.pid, mirror(d.pid), nB * sizeof(int32_t));
-        return PNP_OK;
+    if (total > st.pinned_cap) {
+        if (st.pinned) HIP_TRY(hipHostFree(st.pinned));
+        st.pinned = nullptr;
+        st.pinned_cap = 0;
+        const size_t want = std::max(total + total / 4, kSmallCall);
+        HIP_TRY(hipHostMalloc(&st.pinned, want, hipHostMallocDefault));
+        st.pinned_cap = want;
+        st.pinned_dev = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&st.pinned_dev, st.pinned, 0));
     }
-
-    HIP_TRY(hipMemcpyAsync(d_uv, h.uv, nB * 2 * N * sizeof(T), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_xyz, h.xyz, xyz_elems * sizeof(T), hipMemcpyHostToDevice, s));
-    rc = run(d, B, s);
+    Carver host(st.pinned), dv(st.pinned_dev);
+    auto both = [&](auto tag, size_t count, auto *&host_ptr) {
+        using E = decltype(tag);
+        host_ptr = host.take<E>(count);
+        return dv.take<E>(count);
+    };
+    SolveIO<T> d;
+    T *m_uv, *m_xyz, *m_R, *m_t, *m_res = nullptr, *m_rpy = nullptr;
+    int32_t *m_iters = nullptr, *m_pid = nullptr;
+    d.uv = both(T(), nB * 2 * N, m_uv);
+    d.xyz = both(T(), xyz_elems, m_xyz);
+    d.R = both(T(), nB * 9, m_R);
+    d.t = both(T(), nB * 3, m_t);
+    d.res = h.res ? both(T(), nB, m_res) : nullptr;
+    d.rpy = h.rpy ? both(T(), nB * 3, m_rpy) : nullptr;
+    d.iters = h.iters ? both(int32_t(), nB, m_iters) : nullptr;
+    d.pid = h.pid ? both(int32_t(), nB, m_pid) : nullptr;
+    std::memcpy(m_uv, h.uv, nB * 2 * N * sizeof(T));
+    std::memcpy(m_xyz, h.xyz, xyz_elems * sizeof(T));
+    SyncOnExit guard(s);   // every exit below, error or not, leaves nothing in flight on the buffer
+    const int rc = run(d, B, s);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(h.R, d.R, nB * 9 * sizeof(T), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(h.t, d.t, nB * 3 * sizeof(T), hipMemcpyDeviceToHost, s));
-    if (h.res) HIP_TRY(hipMemcpyAsync(h.res, d.res, nB * sizeof(T), hipMemcpyDeviceToHost, s));
-    if (h.rpy) HIP_TRY(hipMemcpyAsync(h.rpy, d.rpy, nB * 3 * sizeof(T), hipMemcpyDeviceToHost, s));
-    if (h.iters) HIP_TRY(hipMemcpyAsync(h.iters, d.iters, nB * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (h.pid) HIP_TRY(hipMemcpyAsync(h.pid, d.pid, nB * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    guard.armed = false;
+    std::memcpy(h.R, m_R, nB * 9 * sizeof(T));
+    std::memcpy(h.t, m_t, nB * 3 * sizeof(T));
+    if (h.res) std::memcpy(h.res, m_res, nB * sizeof(T));
+    if (h.rpy) std::memcpy(h.rpy, m_rpy, nB * 3 * sizeof(T));
+    if (h.iters) std::memcpy(h.iters, m_iters, nB * sizeof(int32_t));
+    if (h.pid) std::memcpy(h.pid, m_pid, nB * sizeof(int32_t));
     return PNP_OK;
 }
 
