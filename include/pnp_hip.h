@@ -119,9 +119,9 @@ int pnp_lm12_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_st
 /* pnp_qeif_batch_f32 for host pointers (PNP_PTR_HOST), allocating nothing.  It has no
  * counterpart in the reference; it is for callers that cannot allocate device memory: tight
  * serving loops, harnesses that forbid hipMalloc, code that must not change the process's memory
- * footprint.  pnp_qeif_batch_f32 stages host arrays through a device buffer it obtains from
- * hipMalloc (and grows with hipFree + hipMalloc); this entry point stages them through a static
- * device array of PNP_NOALLOC_SCRATCH_BYTES bytes that every GPU the library runs on holds for
+ * footprint.  pnp_qeif_batch_f32 passes pageable host arrays through page-locked buffers it
+ * obtains from hipHostMalloc (and grows with hipHostFree + hipHostMalloc); this entry point copies
+ * them to and from a static device array of PNP_NOALLOC_SCRATCH_BYTES bytes that every GPU the library runs on holds for
  * the life of the process.  It calls no hipMalloc, hipFree or hipHostMalloc.
  *   - Arguments and results are exactly those of pnp_qeif_batch_f32 with ptr_kind = PNP_PTR_HOST
  *     (same kernels, bit-identical outputs); xyz_problem_stride is 0 or 3*N.

@@ -778,9 +778,9 @@ int qeif_impl(const T *uv, const T *xyz, int64_t xyz_stride, int32_t n_patterns,
     });
 }
 
-// The host-pointer QEIF call with its staging in the static array instead of a buffer from
-// hipMalloc: no allocation, no free, no pinned mirror; copies go straight between the caller's
-// arrays and the static array.
+// The host-pointer QEIF call with its staging in the static device array instead of buffers the
+// library allocates: no allocation, no free; copies go straight between the caller's arrays and
+// the static array.
 int qeif_noalloc(const float *uv, const float *xyz, int64_t xyz_stride, const double K[9], int64_t B, int32_t N,
                  const pnp_qeif_params *p, float *R_out, float *t_out, float *res_out, int32_t *iters_out,
                  float *rpy_out, void *hip_stream)
