@@ -10,6 +10,9 @@
 #include <string.h>
 
 #include <atomic>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -458,6 +461,47 @@ int lane_reserve(PipeLane &ln, size_t pinned_bytes)
     return PNP_OK;
 }
 
+// Bulk copy between the caller's arrays and a lane's page-locked buffer with streaming stores:
+// the destination is not read by this CPU next (the GPU reads the buffer, the caller reads its
+// results later), so its lines are written without being fetched first.
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) void copy_streaming_avx2(void *dst, const void *src, size_t n)
+{
+    char *d = static_cast<char *>(dst);
+    const char *s = static_cast<const char *>(src);
+    const size_t head = (32 - (reinterpret_cast<uintptr_t>(d) & 31)) & 31;
+    if (n < 4096 || head > n) {
+        std::memcpy(d, s, n);
+        return;
+    }
+    std::memcpy(d, s, head);
+    d += head; s += head; n -= head;
+    const size_t blocks = n / 128;
+    for (size_t i = 0; i < blocks; ++i) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + 32));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + 64));
+        const __m256i e = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + 96));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(d), a);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(d + 32), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(d + 64), c);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(d + 96), e);
+        s += 128; d += 128;
+    }
+    _mm_sfence();
+    std::memcpy(d, s, n - blocks * 128);
+}
+#endif
+
+void copy_streaming(void *dst, const void *src, size_t n)
+{
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return copy_streaming_avx2(dst, src, n);
+#endif
+    std::memcpy(dst, src, n);
+}
+
 // True when p points into page-locked host memory the HIP runtime knows (hipHostMalloc, a
 // registered range, a pinned torch tensor): memory the kernels can work on over the bus.
 bool is_page_locked(const void *p)
@@ -592,8 +636,8 @@ int pipelined_host_call(Staging &st, int dev, hipStream_t s, int64_t B, int32_t 
                     d.uv = m.uv + first * 2 * N;
                     d.xyz = own_xyz ? m.xyz + first * 3 * N : d_shared_xyz;
                 } else {
-                    std::memcpy(pin + lay.uv, h.uv + first * 2 * N, n * 2 * N * sizeof(T));
-                    if (own_xyz) std::memcpy(pin + lay.xyz, h.xyz + first * 3 * N, n * 3 * N * sizeof(T));
+                    copy_streaming(pin + lay.uv, h.uv + first * 2 * N, n * 2 * N * sizeof(T));
+                    if (own_xyz) copy_streaming(pin + lay.xyz, h.xyz + first * 3 * N, n * 3 * N * sizeof(T));
                     d.uv = reinterpret_cast<const T *>(mp + lay.uv);
                     d.xyz = own_xyz ? reinterpret_cast<const T *>(mp + lay.xyz) : d_shared_xyz;
                 }
@@ -617,12 +661,12 @@ int pipelined_host_call(Staging &st, int dev, hipStream_t s, int64_t B, int32_t 
                 // the lane's buffer is reused by its next chunk, and read below
                 HIP_TRY(hipStreamSynchronize(ln.stream));
                 if (out_locked) continue;
-                std::memcpy(h.R + first * 9, pin + lay.R, n * 9 * sizeof(T));
-                std::memcpy(h.t + first * 3, pin + lay.t, n * 3 * sizeof(T));
-                if (h.res) std::memcpy(h.res + first, pin + lay.res, n * sizeof(T));
-                if (h.rpy) std::memcpy(h.rpy + first * 3, pin + lay.rpy, n * 3 * sizeof(T));
-                if (h.iters) std::memcpy(h.iters + first, pin + lay.iters, n * sizeof(int32_t));
-                if (h.pid) std::memcpy(h.pid + first, pin + lay.pid, n * sizeof(int32_t));
+                copy_streaming(h.R + first * 9, pin + lay.R, n * 9 * sizeof(T));
+                copy_streaming(h.t + first * 3, pin + lay.t, n * 3 * sizeof(T));
+                if (h.res) copy_streaming(h.res + first, pin + lay.res, n * sizeof(T));
+                if (h.rpy) copy_streaming(h.rpy + first * 3, pin + lay.rpy, n * 3 * sizeof(T));
+                if (h.iters) copy_streaming(h.iters + first, pin + lay.iters, n * sizeof(int32_t));
+                if (h.pid) copy_streaming(h.pid + first, pin + lay.pid, n * sizeof(int32_t));
             }
             return PNP_OK;
         };
