@@ -31,7 +31,7 @@
  *   - Host-pointer calls never copy to device memory when they can help it: the kernels are
  *     launched on host memory and read and write it over the bus.  A call all of whose arrays
  *     are page-locked, mapped host memory (hipHostMalloc and the like) is one launch on those
- *     arrays.  Otherwise calls that move 16 MB or more are cut into chunks of about 4 MB which
+ *     arrays.  Otherwise calls that move 8 MB or more are cut into chunks of up to 4 MB which
  *     eight host threads (seven started by the call, joined before it returns) carry through
  *     page-locked buffers and streams of the library's own: copy a chunk of the pageable arrays
  *     in, launch on the buffer, copy the results out, the lanes overlapping each other; a side

@@ -87,7 +87,10 @@ constexpr int64_t kMomentMinBatch = 2048;
 #endif
 constexpr int kPipeLanes = PNP_PIPE_LANES;
 constexpr size_t kPipeChunkBytes = size_t(PNP_PIPE_CHUNK_MB) << 20;   // input bytes per chunk, about
-constexpr size_t kPipeMinBytes = size_t(16) << 20;    // calls moving less than this stay on one stream
+#ifndef PNP_PIPE_MIN_MB
+#define PNP_PIPE_MIN_MB 8
+#endif
+constexpr size_t kPipeMinBytes = size_t(PNP_PIPE_MIN_MB) << 20;    // calls moving less than this stay on one stream
 
 struct PipeLane {
     hipStream_t stream = nullptr;
@@ -550,8 +553,12 @@ template <typename T, typename Run>
 int pipelined_host_call(Staging &st, int dev, hipStream_t s, int64_t B, int32_t N, bool own_xyz,
                         const T *d_shared_xyz, const SolveIO<T> &h, Run run)
 {
+    // chunks of about kPipeChunkBytes of input; smaller ones (down to an eighth) for calls that
+    // would not give every lane two chunks otherwise
     const size_t in_per = (2 * static_cast<size_t>(N) + (own_xyz ? 3 * static_cast<size_t>(N) : 0)) * sizeof(T);
-    int64_t chunk = static_cast<int64_t>(kPipeChunkBytes / in_per);
+    const size_t spread = static_cast<size_t>(B) * in_per / (2 * kPipeLanes);
+    const size_t chunk_bytes = std::min(kPipeChunkBytes, std::max(kPipeChunkBytes / 8, spread));
+    int64_t chunk = static_cast<int64_t>(chunk_bytes / in_per);
     chunk = std::max<int64_t>(1024, chunk & ~int64_t(255));
     const int64_t nchunks = (B + chunk - 1) / chunk;
     const int lanes = static_cast<int>(std::min<int64_t>(kPipeLanes, nchunks));

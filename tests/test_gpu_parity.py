@@ -393,7 +393,7 @@ def test_host_and_device_pointer_paths_agree(golden, torch_dev):
 
 
 def test_large_host_pointer_calls_agree_with_the_device_path(torch_dev):
-    """Host-pointer calls that move 16 MB or more are cut into chunks carried by several host
+    """Host-pointer calls that move 8 MB or more are cut into chunks carried by several host
     threads and streams; every output of every chunk must be what one device-pointer launch over
     the whole batch gives, for sizes that leave a short last chunk and an idle lane."""
     from pnp_solver_test_amd import synth
