@@ -90,12 +90,28 @@ def pack(results):
     )
 
 
+_CELL = {}   # what a worker process of section 15 needs (inherited through fork)
+
+
+def _noise_cell(task):
+    """One (yaw, sigma) cell of the landmark-noise grid: the reference's yaw estimate per noise draw."""
+    yi, si = task
+    est, keys15 = _CELL['est'], _CELL['keys15']
+    clean, s_glob, noise = _CELL['uv_clean'][yi], _CELL['s_glob'][si], _CELL['noise']
+    out = np.zeros(len(noise))
+    for ni in range(len(noise)):
+        pts = (clean + s_glob * noise[ni]).astype(np.float32).astype(np.float64)
+        out[ni] = est.solve_pnp(uv_to_dict(pts, keys15))[4]
+    return yi, si, out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference/scripts')
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
     ap.add_argument('--n-stress', type=int, default=10000)
-    ap.add_argument('--only', default='', help='comma-separated section numbers (1-14); default all')
+    ap.add_argument('--only', default='', help='comma-separated section numbers (1-15); default all')
+    ap.add_argument('--workers', type=int, default=8, help='processes of section 15')
     args = ap.parse_args()
     out_dir = os.path.abspath(args.out)
     os.makedirs(out_dir, exist_ok=True)
@@ -600,6 +616,37 @@ def main():
                 est68.np_point_3d_pretransfer_dict_list[0], LM_key_list=None))
             iters[i] = c68.n
         save('qeif_n68_b.npz', seed=np.int64(50), xyz=P68, uv=uv, iters=iters, **pack(res))
+
+    # ---- 15. the landmark-noise study on its full grid (LM_noise_test.py:141-175, :253-360):
+    #          15 yaw angles x 10 noise levels x 2000 draws = 300,000 reference solves, spread over
+    #          processes; the per-cell statistics of all draws and every tenth draw's estimate are kept
+    if want(15):
+        import multiprocessing as mp
+        n_noise = 2000
+        noise = np.random.default_rng(42).multivariate_normal(np.zeros((2,)), np.eye(2), (n_noise, 15))
+        yaw_list = np.linspace(0.0, 90.0, 15)
+        sigma_list = np.linspace(0.0, 5.0, 10)
+        q = 1.0 / 112.0 * 30.0
+        uv_clean = np.zeros((len(yaw_list), 15, 2))
+        for yi, yaw_i in enumerate(yaw_list):
+            R = gt.get_rotation_matrix_from_Euler(0.0, yaw_i, 0.0, is_degree=True)
+            t = np.array([0.0, 0.0, 1.0]).reshape((3, 1))
+            lm = gt.perspective_projection_golden_landmarks(R, t, is_quantized=True, quantize_q=q,
+                                                            is_returning_homogeneous_vec=False)
+            uv_clean[yi] = np.array([lm[k] for k in keys15])
+        _CELL.update(est=est, keys15=keys15, uv_clean=uv_clean, s_glob=sigma_list / 112.0 * 30.0, noise=noise)
+        yaw_est = np.zeros((len(yaw_list), len(sigma_list), n_noise))
+        tasks = [(yi, si) for yi in range(len(yaw_list)) for si in range(len(sigma_list))]
+        with mp.get_context('fork').Pool(args.workers) as pool:
+            for done, (yi, si, col) in enumerate(pool.imap_unordered(_noise_cell, tasks)):
+                yaw_est[yi, si] = col
+                if done % 10 == 9:
+                    print('  noise grid: %d of %d cells  t=%.0fs' % (done + 1, len(tasks), time.time() - t_start), flush=True)
+        err = yaw_est - yaw_list[:, None, None]
+        save('lm_noise_full.npz', seed=np.int64(42), noise_checksum=np.float64(noise.sum()), yaw_list=yaw_list,
+             sigma_list=sigma_list, quantize_q=np.float64(q), uv_clean=uv_clean, every=np.int64(10),
+             yaw_est_sample=yaw_est[:, :, ::10], mesh_mean=err.mean(axis=2), mesh_std=err.std(axis=2),
+             mesh_mae=np.abs(err).mean(axis=2))
 
     print('done in %.0f s; numpy %s' % (time.time() - t_start, np.__version__))
 

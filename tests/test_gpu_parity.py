@@ -865,10 +865,18 @@ def test_landmark_noise_sweep_driver(golden, torch_dev):
     assert np.abs(r["mesh_mean"] - g["mesh_mean"]).max() <= 1e-3
     assert np.abs(r["mesh_std"] - g["mesh_std"]).max() <= 1e-3
     assert np.abs(r["mesh_mae"] - g["mesh_mae"]).max() <= 1e-3
-    # the full-size grid of the reference driver: 15 yaw x 10 sigma x 2000 noise = 300,000 solves
+    # the full-size grid of the reference driver: 15 yaw x 10 sigma x 2000 noise = 300,000 solves,
+    # against the reference's own run of all of them (every tenth estimate and the cell statistics)
+    f = golden("lm_noise_full")
     noise = np.random.default_rng(42).multivariate_normal(np.zeros(2), np.eye(2), (2000, 15))
-    full = stress.landmark_noise_sweep(np.linspace(0.0, 90.0, 15), np.linspace(0.0, 5.0, 10), noise, P15, idx,
-                                       device=torch_dev)
+    assert noise.sum() == f["noise_checksum"]
+    full = stress.landmark_noise_sweep(f["yaw_list"], f["sigma_list"], noise, P15, idx, device=torch_dev)
+    assert np.array_equal(f["yaw_list"], np.linspace(0.0, 90.0, 15)) and np.array_equal(f["sigma_list"], np.linspace(0.0, 5.0, 10))
+    assert np.abs(full["uv_clean"] - f["uv_clean"]).max() <= 2e-5
+    assert np.abs(full["yaw_est"][:, :, ::int(f["every"])] - f["yaw_est_sample"]).max() <= 2e-3
+    assert np.abs(full["mesh_mean"] - f["mesh_mean"]).max() <= 1e-3
+    assert np.abs(full["mesh_std"] - f["mesh_std"]).max() <= 1e-3
+    assert np.abs(full["mesh_mae"] - f["mesh_mae"]).max() <= 1e-3
     assert full["mesh_mean"].shape == (15, 10) and np.isfinite(full["mesh_std"]).all()
     assert np.all(full["mesh_std"][:, 0] <= 1e-12)                   # sigma = 0: every noise draw is the same problem
     assert np.all(np.diff(full["mesh_std"][0]) > 0.0)                 # spread grows with the noise level

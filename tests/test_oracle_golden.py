@@ -227,6 +227,28 @@ def test_landmark_noise_sweep(golden):
     assert np.abs(err.std(axis=2) - g["mesh_std"]).max() < 1e-8
 
 
+def test_landmark_noise_sweep_full_grid(golden):
+    """The study's own grid, 15 yaw x 10 sigma x 2000 draws, all 300,000 solves run by the reference:
+    the C oracle against every tenth estimate and against the per-cell statistics of all draws."""
+    g = golden("lm_noise_full")
+    noise = np.random.default_rng(int(g["seed"])).multivariate_normal(np.zeros(2), np.eye(2), (2000, 15))
+    assert noise.sum() == g["noise_checksum"]
+    idx = [list(po.PATTERN_ALEXANDER).index(k) for k in po.LM6_KEYS]
+    yaw_est = np.zeros((15, 10, 2000))
+    for yi, yaw in enumerate(g["yaw_list"]):
+        R = po.euler_to_R(0.0, yaw, 0.0, is_degree=True)
+        clean = po.project(P15, K, R, np.array([0.0, 0.0, 1.0]), True, float(g["quantize_q"]))
+        assert np.array_equal(clean, g["uv_clean"][yi])
+        for si, sigma in enumerate(g["sigma_list"]):
+            pts = (clean[None] + (sigma / 112.0 * 30.0) * noise).astype(np.float32).astype(np.float64)
+            yaw_est[yi, si] = c_oracle.qeif_batch(pts[:, idx, :], P6, K)["rpy"][:, 1]
+    assert np.abs(yaw_est[:, :, ::int(g["every"])] - g["yaw_est_sample"]).max() < 1e-7
+    err = yaw_est - g["yaw_list"][:, None, None]
+    assert np.abs(err.mean(axis=2) - g["mesh_mean"]).max() < 1e-8
+    assert np.abs(err.std(axis=2) - g["mesh_std"]).max() < 1e-8
+    assert np.abs(np.abs(err).mean(axis=2) - g["mesh_mae"]).max() < 1e-8
+
+
 def test_compare_epilogue_against_reference_toolbox(golden):
     """The drivers' comparison epilogue against TEST_TOOLBOX.compare_result_and_generate_result_dict
     run on the reference's own stress results."""
