@@ -57,7 +57,7 @@ def _np_dtype(uv, dtype):
 
 
 def solve_pnp_batch(uv, xyz, K, *, method="qeif", params=None, num_it=None, want_rpy=True,
-                    patterns=None, lm_lambda=1e-5, dtype=None, want_res=True):
+                    patterns=None, lm_lambda=1e-5, dtype=None, want_res=True, out=None):
     """Solve B independent PnP problems.
 
     uv       (B, N, 2) pixel coordinates, float32 or float64
@@ -79,6 +79,10 @@ def solve_pnp_batch(uv, xyz, K, *, method="qeif", params=None, num_it=None, want
              (half the bytes) or float64 (the reference's dtype; agrees with it to float64
              round-off).  None follows `uv`: float64 if it is float64, float32 otherwise.
              The arithmetic is float64 either way.
+    out      the dict an earlier call with the same shapes, dtype, options and kind of arrays
+             returned: its arrays are written again and returned, nothing is allocated (a fresh
+             60 MB of NumPy results for a million problems costs about a millisecond of page
+             faults).  ValueError if an array is missing or does not fit.
 
     Returns a dict: R (B,3,3), t (B,3), t3 (B,), res_norm (B,), rpy_deg (B,3) = roll, yaw, pitch
     in the reference's tuple order (if want_rpy), iters (B,) int32 (QEIF only).  Arrays are of
@@ -96,11 +100,21 @@ def solve_pnp_batch(uv, xyz, K, *, method="qeif", params=None, num_it=None, want
     extra = (num_it, float(lm_lambda))
     ft = _np_dtype(uv, dtype)
     if _is_torch(uv):
-        return _solve_torch(lib, uv, xyz, Kc, method, params, extra, want_rpy, patterns, ft, want_res)
-    return _solve_numpy(lib, uv, xyz, Kc, method, params, extra, want_rpy, patterns, ft, want_res)
+        return _solve_torch(lib, uv, xyz, Kc, method, params, extra, want_rpy, patterns, ft, want_res, out)
+    return _solve_numpy(lib, uv, xyz, Kc, method, params, extra, want_rpy, patterns, ft, want_res, out)
 
 
-def _solve_numpy(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, ft, want_res=True):
+def _result_array(out, key, shape, make, fits):
+    """out[key] if the caller handed in results to write again, else a new array from make()."""
+    if out is None:
+        return make()
+    a = out.get(key)
+    if a is None or tuple(a.shape) != tuple(shape) or not fits(a):
+        raise ValueError("out[%r] is missing or is not the %s array this call writes" % (key, tuple(shape)))
+    return a
+
+
+def _solve_numpy(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, ft, want_res=True, reuse=None):
     uv = np.ascontiguousarray(uv, dtype=ft)
     src = patterns if patterns is not None else xyz
     src = np.ascontiguousarray(src, dtype=ft)
@@ -110,12 +124,17 @@ def _solve_numpy(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, f
         B, N, stride, n_pat = int(uv.shape[0]), int(uv.shape[1]), 0, int(src.shape[0])
     else:
         B, N, stride, n_pat = _shapes(uv.shape, src.shape)
-    out = dict(R=np.empty((B, 3, 3), ft), t=np.empty((B, 3), ft))
+    def result(key, shape, dt=ft):
+        return _result_array(reuse, key, shape, lambda: np.empty(shape, dt),
+                             lambda a: isinstance(a, np.ndarray) and a.dtype == dt and a.flags.c_contiguous
+                             and a.flags.writeable)
+
+    out = dict(R=result("R", (B, 3, 3)), t=result("t", (B, 3)))
     if want_res:
-        out["res_norm"] = np.empty(B, ft)
-    rpy = np.empty((B, 3), ft) if want_rpy else None
-    iters = np.empty(B, np.int32) if method == "qeif" else None
-    pid = np.empty(B, np.int32) if patterns is not None else None
+        out["res_norm"] = result("res_norm", (B,))
+    rpy = result("rpy_deg", (B, 3)) if want_rpy else None
+    iters = result("iters", (B,), np.dtype(np.int32)) if method == "qeif" else None
+    pid = result("pattern_id", (B,), np.dtype(np.int32)) if patterns is not None else None
 
     def ptr(a):
         return None if a is None else a.ctypes.data
@@ -123,7 +142,11 @@ def _solve_numpy(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, f
     _call(lib, method, ptr(uv), ptr(src), stride, n_pat, Kc, B, N, params, num_it, ptr(out["R"]),
           ptr(out["t"]), ptr(out.get("res_norm")), ptr(iters), ptr(rpy), ptr(pid), _lib.PTR_HOST, None,
           patterns is not None, ft)
-    out["t3"] = out["t"][:, 2].copy()
+    if reuse is not None and isinstance(reuse.get("t3"), np.ndarray) and reuse["t3"].shape == (B,) and reuse["t3"].dtype == ft:
+        out["t3"] = reuse["t3"]
+        np.copyto(out["t3"], out["t"][:, 2])
+    else:
+        out["t3"] = out["t"][:, 2].copy()
     if rpy is not None:
         out["rpy_deg"] = rpy
     if iters is not None:
@@ -133,7 +156,7 @@ def _solve_numpy(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, f
     return out
 
 
-def _solve_torch(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, ft, want_res=True):
+def _solve_torch(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, ft, want_res=True, reuse=None):
     import torch
     tt = torch.float64 if ft == np.dtype(np.float64) else torch.float32
 
@@ -165,12 +188,17 @@ def _solve_torch(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, f
     dev = uv.device
     where = dict(pin_memory=True) if on_host else dict(device=dev)
     with (torch.cuda.device(torch.cuda.current_device()) if on_host else torch.cuda.device(dev)):
-        out = dict(R=torch.empty((B, 3, 3), dtype=tt, **where), t=torch.empty((B, 3), dtype=tt, **where))
+        def result(key, shape, dt=tt):
+            return _result_array(reuse, key, shape, lambda: torch.empty(shape, dtype=dt, **where),
+                                 lambda a: _is_torch(a) and a.dtype == dt and a.is_contiguous() and
+                                 (a.device.type == "cpu" and a.is_pinned() if on_host else a.device == dev))
+
+        out = dict(R=result("R", (B, 3, 3)), t=result("t", (B, 3)))
         if want_res:
-            out["res_norm"] = torch.empty(B, dtype=tt, **where)
-        rpy = torch.empty((B, 3), dtype=tt, **where) if want_rpy else None
-        iters = torch.empty(B, dtype=torch.int32, **where) if method == "qeif" else None
-        pid = torch.empty(B, dtype=torch.int32, **where) if patterns is not None else None
+            out["res_norm"] = result("res_norm", (B,))
+        rpy = result("rpy_deg", (B, 3)) if want_rpy else None
+        iters = result("iters", (B,), torch.int32) if method == "qeif" else None
+        pid = result("pattern_id", (B,), torch.int32) if patterns is not None else None
         stream = torch.cuda.current_stream().cuda_stream
 
         def ptr(a):

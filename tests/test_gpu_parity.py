@@ -415,6 +415,41 @@ def test_large_host_pointer_calls_agree_with_the_device_path(torch_dev):
     assert all(np.array_equal(d64[k], h64[k]) for k in d64)
 
 
+def test_results_written_into_the_arrays_of_an_earlier_call(golden, torch_dev):
+    """out=: NumPy, device and pinned-host results are written into the arrays of an earlier call
+    (same objects back, new values), and arrays that do not fit are refused."""
+    import torch
+    g, uv = stress_uv6(golden)
+    a, b = uv[:3000], uv[3000:6000]
+    want_b = pnp.solve_pnp_batch(b, P6f, K)
+    first = pnp.solve_pnp_batch(a, P6f, K)
+    held = dict(first)
+    again = pnp.solve_pnp_batch(b, P6f, K, out=first)
+    assert all(again[k] is held[k] for k in held)
+    assert all(np.array_equal(again[k], want_b[k]) for k in want_b)
+    with pytest.raises(ValueError):
+        pnp.solve_pnp_batch(b[:100], P6f, K, out=first)                   # another batch size
+    with pytest.raises(ValueError):
+        pnp.solve_pnp_batch(b.astype(np.float64), P6, K, out=first)       # another dtype
+    with pytest.raises(ValueError):
+        pnp.solve_pnp_batch(b, P6f, K, out={k: v for k, v in first.items() if k != "iters"})
+    d_first = pnp.solve_pnp_batch(to_dev(a, torch_dev), to_dev(P6f, torch_dev), K)
+    ptrs = {k: v.data_ptr() for k, v in d_first.items()}
+    d_again = pnp.solve_pnp_batch(to_dev(b, torch_dev), to_dev(P6f, torch_dev), K, out=d_first)
+    torch.cuda.synchronize()
+    assert all(d_again[k].data_ptr() == ptrs[k] for k in ptrs)
+    assert all(np.array_equal(d_again[k].cpu().numpy(), want_b[k]) for k in want_b)
+    with pytest.raises(ValueError):
+        pnp.solve_pnp_batch(b, P6f, K, out=d_first)                       # device results for a NumPy call
+    h_first = pnp.solve_pnp_batch(torch.from_numpy(a).pin_memory(), torch.from_numpy(P6f).pin_memory(), K)
+    h_again = pnp.solve_pnp_batch(torch.from_numpy(b).pin_memory(), torch.from_numpy(P6f).pin_memory(), K, out=h_first)
+    assert all(h_again[k].is_pinned() and np.array_equal(h_again[k].numpy(), want_b[k]) for k in want_b)
+    dl = pnp.solve_pnp_batch(a, P6f, K, method="dlt", want_rpy=False)
+    dl2 = pnp.solve_pnp_batch(b, P6f, K, method="dlt", want_rpy=False, out=dl)
+    ref = pnp.solve_pnp_batch(b, P6f, K, method="dlt", want_rpy=False)
+    assert all(np.array_equal(dl2[k], ref[k], equal_nan=True) for k in ref)
+
+
 def test_page_locked_host_arrays_are_copied_directly(torch_dev):
     """Host arrays in page-locked memory (here: pinned torch tensors): with every array page-locked
     the kernels work on the caller's memory over the bus (one launch, no copies), with only the
