@@ -196,7 +196,7 @@ class PNP_SOLVER(object):
         return self._finish(out)
 
     def solve_pnp_batch(self, uv, xyz=None, *, method="qeif", params=None, num_it=None, want_rpy=True,
-                        all_patterns=False):
+                        all_patterns=False, out=None):
         """Batched addition (no reference counterpart): uv (B,N,2); xyz (N,3) or (B,N,3), or
         None for the six-landmark subset of the currently selected golden pattern (N must then
         be 6).  all_patterns=True runs every golden pattern and keeps the best per problem.
@@ -205,11 +205,11 @@ class PNP_SOLVER(object):
             patterns = np.stack([self._pattern_array(d, LM_KEY_LIST)
                                  for d in self.np_point_3d_pretransfer_dict_list])
             return _batch.solve_pnp_batch(uv, None, self.np_K_camera_est, method=method, params=params,
-                                          want_rpy=want_rpy, patterns=patterns)
+                                          want_rpy=want_rpy, patterns=patterns, out=out)
         if xyz is None:
             xyz = self._pattern_array(self.get_current_pretransfered_golden_pattern(), LM_KEY_LIST)
         return _batch.solve_pnp_batch(uv, xyz, self.np_K_camera_est, method=method, params=params,
-                                      num_it=num_it, want_rpy=want_rpy)
+                                      num_it=num_it, want_rpy=want_rpy, out=out)
 
     # ---- Euler / projection utilities (host side; conventions in _geometry.py) ----------------
     def get_rotation_matrix_from_Euler(self, roll, yaw, pitch, is_degree=False):
