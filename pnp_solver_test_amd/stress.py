@@ -72,25 +72,39 @@ def small_angle_mask(roll_gt, pitch_gt, yaw_gt, angle_th=30.0):
     return (np.abs(roll_gt) <= angle_th) & (np.abs(pitch_gt) <= angle_th) & (np.abs(yaw_gt) <= angle_th)
 
 
-def class_cell_statistics(classes, est, gt=None, unit_scale=1.0):
-    """Statistics of one quantity in every (distance, roll, pitch, yaw) class cell
-    (TEST_TOOLBOX.get_all_class_seperated_result + get_drpy_statistic, :975-1064).
-    classes: dict of four label arrays as returned by random_stress.  Returns (labels, A):
-    labels = the four label lists in numeric order, A[d, r, p, y, :] = STAT_FIELDS of the cell,
-    NaN where a cell is empty."""
+def class_cell_plan(classes):
+    """What class_cell_statistics needs of the classes alone: the four label lists in numeric
+    order, the shape of the cell array, and the samples grouped by cell."""
     names = ("distance", "roll", "pitch", "yaw")
-    labels = [sorted(set(classes[k].tolist()), key=float) for k in names]
-    index = [np.array([lab.index(v) for v in classes[k].tolist()]) for k, lab in zip(names, labels)]
+    labels, index = [], []
+    for k in names:
+        uniq, inverse = np.unique(np.asarray(classes[k]), return_inverse=True)
+        by_value = sorted(range(len(uniq)), key=lambda i: float(uniq[i]))
+        rank = np.empty(len(uniq), dtype=np.int64)
+        rank[by_value] = np.arange(len(uniq))
+        labels.append(uniq[by_value].tolist())
+        index.append(rank[inverse.reshape(-1)])
     shape = tuple(len(lab) for lab in labels)
     flat = np.ravel_multi_index(index, shape)
     order = np.argsort(flat, kind="stable")                 # keeps sample order inside a cell, as the lists do
+    cuts = np.flatnonzero(np.diff(flat[order])) + 1
+    groups = np.split(order, cuts)
+    return labels, shape, [(np.unravel_index(flat[g[0]], shape), g) for g in groups if len(g)]
+
+
+def class_cell_statistics(classes, est, gt=None, unit_scale=1.0, plan=None):
+    """Statistics of one quantity in every (distance, roll, pitch, yaw) class cell
+    (TEST_TOOLBOX.get_all_class_seperated_result + get_drpy_statistic, :975-1064).
+    classes: dict of four label arrays as returned by random_stress (plan: class_cell_plan(classes),
+    when several quantities share the classes).  Returns (labels, A): labels = the four label
+    lists in numeric order, A[d, r, p, y, :] = STAT_FIELDS of the cell, NaN where a cell is empty."""
+    labels, shape, groups = plan if plan is not None else class_cell_plan(classes)
     est = np.asarray(est, dtype=np.float64)
     gt = None if gt is None else np.asarray(gt, dtype=np.float64)
     A = np.full(shape + (len(STAT_FIELDS),), np.nan)
-    cuts = np.flatnonzero(np.diff(flat[order])) + 1
-    for idx in np.split(order, cuts):
+    for cell, idx in groups:
         st = error_statistics(est[idx], None if gt is None else gt[idx], unit_scale)
-        A[np.unravel_index(flat[idx[0]], shape)] = [st[k] for k in STAT_FIELDS]
+        A[cell] = [st[k] for k in STAT_FIELDS]
     return labels, A
 
 
@@ -130,11 +144,11 @@ def random_stress(count, seed=42, pattern15=None, lm_rows=None, K=synth.K_DEFAUL
                             roll=error_statistics(res["rpy_deg"][m, 0], roll[m]),
                             pitch=error_statistics(res["rpy_deg"][m, 2], pitch[m]),
                             yaw=error_statistics(res["rpy_deg"][m, 1], yaw[m]))
-    cell_stats = {}
+    cell_stats, plan = {}, class_cell_plan(classes)
     for name, e_, g_, scale in (("depth", res["t3"], t[:, 2], 100.0), ("roll", res["rpy_deg"][:, 0], roll, 1.0),
                                 ("pitch", res["rpy_deg"][:, 2], pitch, 1.0), ("yaw", res["rpy_deg"][:, 1], yaw, 1.0),
                                 ("LM_GT_error_average_normalize", res["lm_err_avg"][:, 0], None, 1.0)):
-        cell_labels, cell_stats[name] = class_cell_statistics(classes, e_, g_, scale)     # TEST_TOOLBOX.py:1240-1245
+        cell_labels, cell_stats[name] = class_cell_statistics(classes, e_, g_, scale, plan)     # TEST_TOOLBOX.py:1240-1245
     res["cell_labels"], res["cell_stats"] = cell_labels, cell_stats
     return dict(roll_gt=roll, pitch_gt=pitch, yaw_gt=yaw, t_gt=t, uv=uv_all.detach().cpu().numpy(), classes=classes,
                 passed=passed, pass_count=passed.sum(axis=1), failed_sample_count=int(failed.sum()),
