@@ -383,16 +383,19 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment
         if (tid < nprob) {
             // two points per trip, their registers alternating: the LDS reads of one point are
             // in flight while the other is accumulated (a single rotating pair of variables gets
-            // folded by the compiler into read-then-use within one trip)
+            // folded by the compiler into read-then-use within one trip).  The trip has no
+            // branch: behind a condition the second point's reads are sunk to where they are
+            // used and waited for on the spot; an odd last point is taken after the loop.
             Staged pa, pb;
             fetch(c0, 0, pa);
 #pragma unroll 1
-            for (int i = 0; i < cn; i += 2) {
-                fetch(c0, min(i + 1, cn - 1), pb);
+            for (int i = 0; i + 1 < cn; i += 2) {
+                fetch(c0, i + 1, pb);
                 accumulate(pa);
                 fetch(c0, min(i + 2, cn - 1), pa);
-                if (i + 1 < cn) accumulate(pb);
+                accumulate(pb);
             }
+            if (cn & 1) accumulate(pa);
         }
     }
     if (tid >= nprob) return;  // no barrier follows
