@@ -81,6 +81,16 @@ for label, kern, B, N, own in LAUNCHES:
         s["fetch_calibration"] = ("FETCH_SIZE calibrated on this access shape (scripts/probes/fetch_calibration.hip): "
                                   "a single read of the inputs would count %.0f bytes" % counted_if_read_once)
         s["read_bytes_over_input"] = round(ratio, 4)
+        if ratio < 1.0:
+            # Fewer requests than the calibration loads of the same shape: those ask for most lines
+            # in two parts a chunk period apart and fetch them twice, while this kernel finds the
+            # second part in L2 (with a shared pattern a chunk period touches less than the L2
+            # holds).  FETCH_SIZE is requests x 64 bytes and a request brings 64 or 128 bytes, so
+            # the bytes lie between FETCH_SIZE and twice that; the input is read from beyond the L2
+            # at least once per launch (it is 4x the L2s), so the input size is what is reported.
+            s["read_bytes_bracket"] = [round(s["FETCH_SIZE"] * 1024), round(2 * s["FETCH_SIZE"] * 1024)]
+            s["fetch_calibration"] += "; calibrated ratio %.4f < 1: see read_bytes_bracket, reported as the input read once" % ratio
+            ratio = 1.0
         s["fetch_bytes_calibrated"] = ratio * in_bytes
         s["hbm_bytes_per_launch"] = s["fetch_bytes_calibrated"] + s["write_bytes"]
         del s["fetch_bytes_2x"], s["fetch_2x_over_input"]
