@@ -309,3 +309,17 @@ def test_face_variation_draws_match_reference_run(golden, tag, random_pose):
         assert np.all(np.diff(a["top_singular_values"]) <= 0)
         assert np.allclose(np.linalg.norm(a["top_directions"].reshape(5, -1), axis=1), 1.0)
         assert a["value_max"] == g["abs_err"][:, c].max()
+
+
+def test_result_arrays_of_an_earlier_call_are_checked_before_reuse():
+    """solve_pnp_batch(out=...): an array is taken again only if it has the shape, element type
+    and layout the call writes; anything else is refused, not replaced."""
+    from pnp_solver_test_amd.batch import _result_array
+    fits = lambda a: isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags.c_contiguous  # noqa: E731
+    fresh = _result_array(None, "R", (4, 3, 3), lambda: np.empty((4, 3, 3), np.float32), fits)
+    assert fresh.shape == (4, 3, 3)
+    held = dict(R=fresh, t=np.empty((4, 3), np.float64), wide=np.empty((4, 6), np.float32)[:, ::2])
+    assert _result_array(held, "R", (4, 3, 3), None, fits) is fresh
+    for key, shape in (("R", (5, 3, 3)), ("t", (4, 3)), ("wide", (4, 3)), ("missing", (4,))):
+        with pytest.raises(ValueError):
+            _result_array(held, key, shape, None, fits)
