@@ -109,8 +109,10 @@ int pnp_dlt_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_str
  * is_hc0_4_6_linear=False, is_hc1_linear=True) and reconstruction EKF2_reconstruct_R_t_m1
  * (:3500-3540): num_it iterations (reference: 14, no early exit) of
  * dx = (J^T J + lambda I)^-1 J^T (z - h) with lambda = 1e-5 in the reference.  res_out is the
- * reprojection part of the residual at the last linearisation point (:2681).  N is limited by
- * LDS (64 problems per workgroup): (2N + 3N) elements per problem must fit 48 KB. */
+ * reprojection part of the residual at the last linearisation point (:2681).  A wavefront
+ * solves 64 problems while their (2N + 3N) elements each fit 48 KB of LDS (N <= 38 with float32
+ * arrays and a pattern per problem), and half, a quarter, ... as many beyond that, at the same
+ * cost per wavefront; every N up to pnp_max_points() is accepted. */
 int pnp_lm12_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_stride,
                        const double K[9], int64_t B, int32_t N, double lambda, int32_t num_it,
                        float *R_out, float *t_out, float *res_out, float *rpy_out,

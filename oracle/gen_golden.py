@@ -110,7 +110,7 @@ def main():
     ap.add_argument('--ref', default='/root/reference/scripts')
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
     ap.add_argument('--n-stress', type=int, default=10000)
-    ap.add_argument('--only', default='', help='comma-separated section numbers (1-15); default all')
+    ap.add_argument('--only', default='', help='comma-separated section numbers (1-16); default all')
     ap.add_argument('--workers', type=int, default=8, help='processes of section 15')
     args = ap.parse_args()
     out_dir = os.path.abspath(args.out)
@@ -647,6 +647,30 @@ def main():
              sigma_list=sigma_list, quantize_q=np.float64(q), uv_clean=uv_clean, every=np.int64(10),
              yaw_est_sample=yaw_est[:, :, ::10], mesh_mean=err.mean(axis=2), mesh_std=err.std(axis=2),
              mesh_mae=np.abs(err).mean(axis=2))
+
+    # ---- 16. the 12-state LM solver on 68 points (the pattern of section 14's second file)
+    if want(16):
+        import contextlib
+        import io
+        n = 128
+        P68 = np.random.default_rng(1).uniform([-0.09, -0.06, -0.05], [0.09, 0.10, 0.03], (68, 3))
+        P68 = np.round(P68 * 4096.0) / 4096.0           # on a 2^-12 m grid: exact in float32
+        keys68 = ['q%02d' % i for i in range(68)]
+        pat68 = {k: P68[i].tolist() for i, k in enumerate(keys68)}
+        with contextlib.redirect_stdout(io.StringIO()):
+            gt68 = PNPS.PNP_SOLVER(K, [pat68], verbose=False)
+            lm68 = PNPS.PNP_SOLVER(K, [pat68], verbose=False)
+        rng = np.random.default_rng(51)
+        uv = np.zeros((n, 68, 2), dtype=np.float32)
+        res = []
+        for i in range(n):
+            roll, pitch, yaw, t = draw_stress_pose(rng)
+            R = gt68.get_rotation_matrix_from_Euler(roll, yaw, pitch, is_degree=True)
+            img = gt68.perspective_projection_golden_landmarks(R, t, is_quantized=True, quantize_q=0.25)
+            uv[i] = dict_to_uv(img, keys68).astype(np.float32)
+            res.append(lm68.solve_pnp_LM_single_pattern(uv_to_dict(uv[i].astype(np.float64), keys68),
+                                                        lm68.np_point_3d_pretransfer_dict_list[0]))
+        save('lm12_n68.npz', seed=np.int64(51), uv=uv, xyz=P68, **pack(res))
 
     print('done in %.0f s; numpy %s' % (time.time() - t_start, np.__version__))
 

@@ -427,15 +427,32 @@ int launch_lm12(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, co
                 int64_t B, int N, double lambda, int num_it, T *R, T *t, T *res, T *rpy)
 {
     if (B == 0) return PNP_OK;
-    const size_t pb = pnp::kLmBlock;
-    const size_t lds = (pb * 2 * N + (xyz_stride ? pb * 3 * N : static_cast<size_t>(3) * N)) * sizeof(T);
-    if (lds > static_cast<size_t>(kLdsBudget))
-        return fail(PNP_E_ARG, "N = %d needs %zu bytes of LDS per workgroup in the LM solver (max %d)", N, lds,
-                    kLdsBudget);
-    const int64_t nblk = (B + pnp::kLmBlock - 1) / pnp::kLmBlock;
+    // problems per wavefront: 64, or the largest power-of-two fraction whose points fit the LDS budget
+    int lpi = 1;
+    auto lds_for = [&](int l) {
+        const size_t pb = pnp::kLmBlock / l;
+        return (pb * 2 * N + (xyz_stride ? pb * 3 * N : static_cast<size_t>(3) * N)) * sizeof(T);
+    };
+    while (lpi < 64 && lds_for(lpi) > static_cast<size_t>(kLdsBudget)) lpi *= 2;
+    const size_t lds = lds_for(lpi);
+    if (lds > 64 * 1024)
+        return fail(PNP_E_ARG, "N = %d needs %zu bytes of LDS per workgroup in the LM solver (max 65536)", N, lds);
+    const int64_t pb = pnp::kLmBlock / lpi;
+    const int64_t nblk = (B + pb - 1) / pb;
     if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
-    hipLaunchKernelGGL((pnp::lm12_kernel<T>), dim3(static_cast<unsigned>(nblk)), dim3(pnp::kLmBlock), lds, s, uv,
-                       xyz, xyz_stride, ki, B, N, lambda, num_it, R, t, res, rpy);
+#define PNP_L(LPI_)                                                                                              \
+    hipLaunchKernelGGL((pnp::lm12_kernel<T, LPI_>), dim3(static_cast<unsigned>(nblk)), dim3(pnp::kLmBlock), lds, s, \
+                       uv, xyz, xyz_stride, ki, B, N, lambda, num_it, R, t, res, rpy)
+    switch (lpi) {
+    case 1: PNP_L(1); break;
+    case 2: PNP_L(2); break;
+    case 4: PNP_L(4); break;
+    case 8: PNP_L(8); break;
+    case 16: PNP_L(16); break;
+    case 32: PNP_L(32); break;
+    default: PNP_L(64); break;
+    }
+#undef PNP_L
     HIP_TRY(hipGetLastError());
     return PNP_OK;
 }

@@ -574,14 +574,17 @@ __global__ __launch_bounds__(kSolveBlock<T>, PNP_DLT_WAVES) void dlt_kernel(
 
 constexpr int kLmBlock = 64;  // one wavefront per workgroup: the 12x12 system needs the whole register file
 
-// 12-state LM over B problems, one lane per problem.
-template <typename T>
+// 12-state LM over B problems, one lane per problem.  With many points a wavefront's 64 problems
+// do not fit the LDS a workgroup may take; the workgroup then stages 64 / LPI problems and LPI
+// neighbouring lanes solve the same one (the first of them stores it): fewer problems per
+// wavefront, the same arithmetic per problem.
+template <typename T, int LPI>
 __global__ __launch_bounds__(kLmBlock) void lm12_kernel(
     const T *__restrict__ uv, const T *__restrict__ xyz, int64_t xyz_stride, KinvRows ki, int64_t B, int N,
     double lam, int num_it, T *__restrict__ R_out, T *__restrict__ t_out, T *__restrict__ res_out,
     T *__restrict__ rpy_out)
 {
-    const Slot<T> s = stage_problems<1, kLmBlock>(uv, xyz, xyz_stride, 1, ki, B, N);
+    const Slot<T> s = stage_problems<LPI, kLmBlock>(uv, xyz, xyz_stride, 1, ki, B, N);
     double R[9], t[3], res;
     lm12_solve(s.pts, N, lam, num_it, R, t, res);
     if (s.store) {

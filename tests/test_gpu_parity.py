@@ -960,6 +960,33 @@ def test_lm12_against_reference(golden, torch_dev, tag, keys):
     assert rot_angle(R, g["R"][i])[0] <= ANG_TOL
 
 
+def test_lm12_on_68_points(golden, torch_dev):
+    """Many points: a wavefront's 64 problems no longer fit a workgroup's LDS and the launch
+    stages fewer problems per wavefront (32 with float32 arrays and a pattern per problem, 16
+    with float64).  Against the reference's own run on a 68-point pattern that is exact in
+    float32, wherever its iteration has settled (final residual below 1; 119 of 128 poses)."""
+    g = golden("lm12_n68")
+    P = g["xyz"]
+    assert np.array_equal(P.astype(np.float32).astype(np.float64), P)
+    settled = np.isfinite(g["R"]).all(axis=(1, 2)) & (g["res_norm"] < 1.0)
+    assert settled.sum() >= 110
+    own = np.broadcast_to(P, (len(g["uv"]), 68, 3))
+    shared32 = solve_dev(g["uv"], P.astype(np.float32), torch_dev, method="lm12")
+    own32 = solve_dev(g["uv"], own.astype(np.float32), torch_dev, method="lm12")
+    assert np.array_equal(shared32["R"], own32["R"], equal_nan=True) and np.array_equal(shared32["t"], own32["t"], equal_nan=True)
+    assert rot_angle(own32["R"], g["R"])[settled].max() <= ANG_TOL
+    assert rel_t(own32["t"], g["t"])[settled].max() <= RELT_TOL
+    assert np.abs(own32["res_norm"] - g["res_norm"])[settled].max() <= 1e-5
+    own64 = solve_dev64(g["uv"], own, torch_dev, method="lm12")
+    assert np.abs(own64["R"] - g["R"])[settled].max() <= DR_F64
+    assert rel_t(own64["t"], g["t"])[settled].max() <= RELT_F64
+    host = pnp.solve_pnp_batch(g["uv"][:40], own[:40].astype(np.float32), K, method="lm12")
+    assert np.array_equal(host["R"], own32["R"][:40], equal_nan=True)
+    i = int(np.flatnonzero(settled)[0])
+    orc = po.lm12_solve(g["uv"][i].astype(np.float64), P, K)
+    assert np.array_equal(orc["R"], g["R"][i])               # the oracle is the reference, bit for bit
+
+
 # ---------------------------------------------------------------------------------------------
 # the float64 flavour of the entry points: the reference's own dtype end to end
 # ---------------------------------------------------------------------------------------------

@@ -208,6 +208,14 @@ def test_lm12(golden, tag, keys):
         assert q["res_norm"] == g["res_norm"][i]
 
 
+def test_lm12_on_68_points(golden):
+    g = golden("lm12_n68")
+    for i in range(0, 128, 8):
+        q = po.lm12_solve(g["uv"][i].astype(np.float64), g["xyz"], K)
+        assert np.array_equal(q["R"], g["R"][i]) and np.array_equal(q["t"], g["t"][i])
+        assert q["res_norm"] == g["res_norm"][i]
+
+
 def test_landmark_noise_sweep(golden):
     g = golden("lm_noise_small")
     noise = np.random.default_rng(int(g["seed"])).multivariate_normal(np.zeros(2), np.eye(2), (2000, 15))
