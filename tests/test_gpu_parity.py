@@ -960,6 +960,37 @@ def test_lm12_against_reference(golden, torch_dev, tag, keys):
     assert rot_angle(R, g["R"][i])[0] <= ANG_TOL
 
 
+@pytest.mark.parametrize("N", [130, 512])
+def test_every_solver_up_to_the_maximum_point_count(torch_dev, N):
+    """Point counts far above the configurations of the benchmark, up to pnp_max_points(): every
+    solver takes them in both element types with shared and per-problem patterns; QEIF and DLT
+    agree with the C oracle as they do at six points, LM results are finite and the same for
+    both pattern layouts."""
+    from pnp_solver_test_amd import synth
+    assert _lib.load().pnp_max_points() == 512
+    rng = np.random.default_rng(N)
+    P = np.round(rng.uniform([-0.09, -0.06, -0.05], [0.09, 0.10, 0.03], (N, 3)) * 4096.0) / 4096.0
+    uv, _ = synth.stress_batch(300, seed=N, pattern=P, K=K, is_quantized=True)
+    ref_q = c_oracle.qeif_batch(uv.astype(np.float64), P, K)
+    ref_d = c_oracle.dlt_batch(uv.astype(np.float64), P, K)
+    own = np.broadcast_to(P, (len(uv), N, 3))
+    for solve, cast, tol in ((solve_dev, np.float32, 1e-6), (solve_dev64, np.float64, 1e-10)):
+        lm = []
+        for xyz in (P, own):
+            q = solve(uv, np.ascontiguousarray(xyz.astype(cast)), torch_dev)
+            assert np.array_equal(q["iters"], ref_q["iters"])
+            assert np.abs(q["R"] - ref_q["R"]).max() <= tol and rel_t(q["t"], ref_q["t"]).max() <= tol
+            d = solve(uv, np.ascontiguousarray(xyz.astype(cast)), torch_dev, method="dlt")
+            m = dlt_comparable(d["R"], ref_d["R"], ref_d["margins"])
+            assert m.mean() >= 0.98
+            assert np.abs(d["R"] - ref_d["R"])[m].max() <= tol and rel_t(d["t"][m], ref_d["t"][m]).max() <= tol
+            lm.append(solve(uv, np.ascontiguousarray(xyz.astype(cast)), torch_dev, method="lm12"))
+            assert np.isfinite(lm[-1]["R"]).all()
+        assert np.array_equal(lm[0]["R"], lm[1]["R"]) and np.array_equal(lm[0]["t"], lm[1]["t"])
+    two = pnp.solve_pnp_batch(to_dev(uv, torch_dev), None, K, patterns=to_dev(np.stack([P * np.array([1.3, 1.0, 0.8]), P]).astype(np.float32), torch_dev))
+    assert (two["pattern_id"].cpu().numpy() == 1).mean() >= 0.99       # the distorted pattern loses
+
+
 def test_lm12_on_68_points(golden, torch_dev):
     """Many points: a wavefront's 64 problems no longer fit a workgroup's LDS and the launch
     stages fewer problems per wavefront (32 with float32 arrays and a pattern per problem, 16
