@@ -292,14 +292,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the solver has no CPU path")
-    dev_index = local_rank
     if local_rank >= torch.cuda.device_count():
-        # a launcher that hands every rank its own single visible device (HIP_VISIBLE_DEVICES per rank)
-        if torch.cuda.device_count() != 1:
-            raise SystemExit("rank %d wants device %d but only %d are visible" % (rank, local_rank, torch.cuda.device_count()))
-        dev_index = 0
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+        raise SystemExit("rank %d wants device %d but only %d are visible" % (rank, local_rank, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     distributed = "RANK" in os.environ          # one of the ranks of torch.distributed.run, any world size
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
