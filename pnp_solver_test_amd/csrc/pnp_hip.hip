@@ -339,10 +339,25 @@ int launch_qeif_moment(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_str
     return PNP_OK;
 }
 
+// Experiment switch (environment PNP_ROWS_STAGED=1): six-point launches through the LDS-staged
+// kernels even where every lane could read its own rows.
+std::atomic<bool> g_rows_staged{getenv("PNP_ROWS_STAGED") != nullptr && getenv("PNP_ROWS_STAGED")[0] == '1'};
+
+// True when the lanes of a six-point, one-lane-per-problem launch may read their rows themselves
+// (pnp::OwnRows6): rows in device memory (over the bus the partial cache lines of such loads would
+// be fetched once per load), pixel rows 16-byte aligned, pattern rows aligned to two elements.
+template <typename T>
+bool own_rows_ok(const T *uv, const T *xyz, int64_t xyz_stride, int lpi, int N, bool rows_on_device)
+{
+    return rows_on_device && lpi == 1 && N == 6 && (xyz_stride == 0 || xyz_stride >= 18) && xyz_stride % 2 == 0 &&
+           reinterpret_cast<uintptr_t>(uv) % 16 == 0 && reinterpret_cast<uintptr_t>(xyz) % (2 * sizeof(T)) == 0 &&
+           !g_rows_staged.load();
+}
+
 template <typename T>
 int launch_qeif(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, int n_patterns,
                 const pnp::KinvRows &ki, int64_t B, int N, const pnp::QeifParams &p, T *R, T *t, T *res,
-                int32_t *iters, T *rpy, int32_t *pid, int64_t plan_B = -1)
+                int32_t *iters, T *rpy, int32_t *pid, int64_t plan_B = -1, bool rows_on_device = true)
 {
     if (B == 0) return PNP_OK;
     // plan_B: the size of the batch this launch is a chunk of; form and lanes per problem are
@@ -363,6 +378,12 @@ int launch_qeif(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, in
     const int64_t nblk = (B + pb - 1) / pb;
     if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
     const dim3 grid(static_cast<unsigned>(nblk));
+    if (n_patterns == 1 && own_rows_ok(uv, xyz, xyz_stride, lpi, N, rows_on_device)) {
+        hipLaunchKernelGGL((pnp::qeif_rows6_kernel<T>), grid, dim3(block), 0, s, uv, xyz, xyz_stride, ki, B, p, R, t, res,
+                           iters, rpy, pid);
+        HIP_TRY(hipGetLastError());
+        return PNP_OK;
+    }
 #define PNP_Q(LPI_, NCT_)                                                                                    \
     do {                                                                                                     \
         if (n_patterns > 1)                                                                                  \
@@ -391,7 +412,8 @@ int launch_qeif(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, in
 
 template <typename T>
 int launch_dlt(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, const pnp::KinvRows &ki,
-               int64_t B, int N, int num_it, T *R, T *t, T *res, T *rpy, int64_t plan_B = -1)
+               int64_t B, int N, int num_it, T *R, T *t, T *res, T *rpy, int64_t plan_B = -1,
+               bool rows_on_device = true)
 {
     if (B == 0) return PNP_OK;
     if (plan_B < B) plan_B = B;   // see launch_qeif
@@ -403,6 +425,12 @@ int launch_dlt(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, con
     const int64_t nblk = (B + pb - 1) / pb;
     if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
     const dim3 grid(static_cast<unsigned>(nblk));
+    if (own_rows_ok(uv, xyz, xyz_stride, lpi, N, rows_on_device)) {
+        hipLaunchKernelGGL((pnp::dlt_rows6_kernel<T>), grid, dim3(block), 0, s, uv, xyz, xyz_stride, ki, B, N, num_it, R,
+                           t, res, rpy);
+        HIP_TRY(hipGetLastError());
+        return PNP_OK;
+    }
 #define PNP_D(LPI_, NCT_)                                                                                \
     hipLaunchKernelGGL((pnp::dlt_kernel<LPI_, NCT_, T>), grid, dim3(block), lds, s, uv, xyz, xyz_stride, \
                        ki, B, N, num_it, R, t, res, rpy)
@@ -842,7 +870,7 @@ int qeif_impl(const T *uv, const T *xyz, int64_t xyz_stride, int32_t n_patterns,
     SolveIO<T> h{uv, xyz, R_out, t_out, res_out, rpy_out, iters_out, pid_out};
     return with_host_staging<T>(s, B, N, xyz_elems, xyz_stride != 0, h, [&](const SolveIO<T> &d, int64_t count, hipStream_t on) {
         return launch_qeif<T>(on, d.uv, d.xyz, xyz_stride, n_patterns, ki, count, N, q, d.R, d.t, d.res, d.iters,
-                              d.rpy, d.pid, B);
+                              d.rpy, d.pid, B, /*rows_on_device=*/false);
     });
 }
 
@@ -923,7 +951,8 @@ int dlt_impl(const T *uv, const T *xyz, int64_t xyz_stride, const double K[9], i
     const size_t xyz_elems = xyz_stride ? static_cast<size_t>(B) * 3 * N : static_cast<size_t>(3) * N;
     SolveIO<T> h{uv, xyz, R_out, t_out, res_out, rpy_out, nullptr, nullptr};
     return with_host_staging<T>(s, B, N, xyz_elems, xyz_stride != 0, h, [&](const SolveIO<T> &d, int64_t count, hipStream_t on) {
-        return launch_dlt<T>(on, d.uv, d.xyz, xyz_stride, ki, count, N, num_it, d.R, d.t, d.res, d.rpy, B);
+        return launch_dlt<T>(on, d.uv, d.xyz, xyz_stride, ki, count, N, num_it, d.R, d.t, d.res, d.rpy, B,
+                             /*rows_on_device=*/false);
     });
 }
 

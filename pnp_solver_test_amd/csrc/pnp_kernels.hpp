@@ -79,6 +79,48 @@ struct RegPoints {
     }
 };
 
+// The six points of one problem read by the lane that solves it, straight from memory: the pixel
+// row (12 elements) in 16-byte pieces, the pattern row (18 elements) in pieces of two elements.
+// Neighbouring lanes read neighbouring rows, so the pieces of one load instruction lie 48 / 72
+// bytes apart (float32) and the instructions of one row share their cache lines; nothing passes
+// through LDS and no lane waits at a barrier.  The pixel row must be 16-byte aligned, the pattern
+// row aligned to two elements.
+template <typename T>
+struct OwnRows6 {
+    static constexpr int UE = 16 / static_cast<int>(sizeof(T));
+    typedef T UvPiece __attribute__((ext_vector_type(UE)));
+    typedef T XyzPiece __attribute__((ext_vector_type(2)));
+    T uv[12], xyz[18];
+    KinvRows ki;
+    __device__ __forceinline__ OwnRows6(const T *uv_row, const T *xyz_row, const KinvRows &k) : ki(k)
+    {
+        const UvPiece *pu = reinterpret_cast<const UvPiece *>(uv_row);
+#pragma unroll
+        for (int i = 0; i < 12 / UE; ++i) {
+            const UvPiece q = pu[i];
+#pragma unroll
+            for (int e = 0; e < UE; ++e) uv[UE * i + e] = q[e];
+        }
+        const XyzPiece *px = reinterpret_cast<const XyzPiece *>(xyz_row);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const XyzPiece q = px[i];
+            xyz[2 * i] = q[0];
+            xyz[2 * i + 1] = q[1];
+        }
+    }
+    __device__ __forceinline__ void operator()(int i, double &X, double &Y, double &Z, double &bx,
+                                               double &by) const
+    {
+        const double u = static_cast<double>(uv[2 * i]), v = static_cast<double>(uv[2 * i + 1]);
+        bx = __builtin_fma(ki.a00, u, __builtin_fma(ki.a01, v, ki.a02));
+        by = __builtin_fma(ki.a10, u, __builtin_fma(ki.a11, v, ki.a12));
+        X = static_cast<double>(xyz[3 * i]);
+        Y = static_cast<double>(xyz[3 * i + 1]);
+        Z = static_cast<double>(xyz[3 * i + 2]);
+    }
+};
+
 // What a lane knows about its place in the workgroup after staging.
 template <typename T>
 struct Slot {
@@ -205,6 +247,31 @@ __global__ __launch_bounds__(kSolveBlock<T>, PNP_QEIF_WAVES) void qeif_kernel(
         if (iters_out) iters_out[s.problem] = iters;
         if (rpy_out) store_rpy(s.problem, R, rpy_out);
         if (pattern_id_out) pattern_id_out[s.problem] = best;
+    }
+}
+
+// qeif_kernel<1, 6, T, false> without the LDS image: six points, one lane per problem, one pattern
+// (per problem, xyz_stride >= 18, or shared, xyz_stride == 0), rows in device memory and aligned as
+// OwnRows6 asks.  Same arithmetic on the same values, so the same bits; the launch is shorter by
+// the staging loop, the barrier and the LDS round trip.
+template <typename T>
+__global__ __launch_bounds__(kSolveBlock<T>, PNP_QEIF_WAVES) void qeif_rows6_kernel(
+    const T *__restrict__ uv, const T *__restrict__ xyz, int64_t xyz_stride, KinvRows ki, int64_t B, QeifParams p,
+    T *__restrict__ R_out, T *__restrict__ t_out, T *__restrict__ res_out, int32_t *__restrict__ iters_out,
+    T *__restrict__ rpy_out, int32_t *__restrict__ pattern_id_out)
+{
+    const int64_t slot = static_cast<int64_t>(blockIdx.x) * kSolveBlock<T> + threadIdx.x;
+    const int64_t problem = min(slot, B - 1);  // idle lanes of the last workgroup redo the last problem
+    const RegPoints<6> rp(OwnRows6<T>(uv + problem * 12, xyz + problem * xyz_stride, ki));
+    double R[9], t[3], res;
+    int iters;
+    qeif_solve<1, 6>(rp, 6, 0, p, R, t, res, iters);
+    if (slot < B) {
+        store_pose(problem, R, t, R_out, t_out);
+        if (res_out) res_out[problem] = static_cast<T>(res);
+        if (iters_out) iters_out[problem] = iters;
+        if (rpy_out) store_rpy(problem, R, rpy_out);
+        if (pattern_id_out) pattern_id_out[problem] = 0;
     }
 }
 
@@ -569,6 +636,31 @@ __global__ __launch_bounds__(kSolveBlock<T>, PNP_DLT_WAVES) void dlt_kernel(
         store_pose(s.problem, R, t, R_out, t_out);
         if (res_out) res_out[s.problem] = static_cast<T>(res);
         if (rpy_out) store_rpy(s.problem, R, rpy_out);
+    }
+}
+
+// dlt_kernel<1, 6, T> without the LDS image (see qeif_rows6_kernel).  A problem whose normal
+// equations were rank-deficient is solved again through the pseudo-inverse with its points read
+// from memory; N (= 6) comes as an argument so that this rare path stays a loop over the points.
+template <typename T>
+__global__ __launch_bounds__(kSolveBlock<T>, PNP_DLT_WAVES) void dlt_rows6_kernel(
+    const T *__restrict__ uv, const T *__restrict__ xyz, int64_t xyz_stride, KinvRows ki, int64_t B, int N,
+    int num_it, T *__restrict__ R_out, T *__restrict__ t_out, T *__restrict__ res_out, T *__restrict__ rpy_out)
+{
+    const int64_t slot = static_cast<int64_t>(blockIdx.x) * kSolveBlock<T> + threadIdx.x;
+    const int64_t problem = min(slot, B - 1);
+    const T *uv_row = uv + problem * 12, *xyz_row = xyz + problem * xyz_stride;
+    const RegPoints<6> rp(OwnRows6<T>(uv_row, xyz_row, ki));
+    double R[9], t[3], res;
+    const bool sound = dlt_solve<1, 6, false>(rp, 6, 0, num_it, res_out != nullptr, R, t, res);
+    if (!sound) {
+        const LdsPoints<T> in_mem{uv_row, xyz_row, ki};
+        dlt_solve<1, 0, true>(in_mem, N, 0, num_it, res_out != nullptr, R, t, res);
+    }
+    if (slot < B) {
+        store_pose(problem, R, t, R_out, t_out);
+        if (res_out) res_out[problem] = static_cast<T>(res);
+        if (rpy_out) store_rpy(problem, R, rpy_out);
     }
 }
 
