@@ -411,7 +411,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
-                "kernel": "pnp::qeif_kernel<1,6>",
+                "kernel": "pnp::qeif_rows6_kernel<float>",
                 "kernel_ms": round(kernel_ms, 4),
                 "kernel_ms_min": round(sampled[0], 4) if sampled else None,
                 "kernel_ms_median": round(sampled[len(sampled) // 2], 4) if sampled else None,
@@ -451,7 +451,7 @@ def main():
                 valu_fp64_TFLOPs=round(B * dlt_flops(6) / (ms * 1e-3) / 1e12, 2),
                 roofline=dict(bound="hbm", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                               frac=round(gbs / HBM_PEAK_GBS, 5), traffic=traffic_of("dlt_n6_b1m_per_problem_xyz_bytes_per_launch"),
-                              kernel="pnp::dlt_kernel<1,6>", kernel_ms=round(ms, 4), bytes_per_solve=bytes_per_solve))
+                              kernel="pnp::dlt_rows6_kernel<float>", kernel_ms=round(ms, 4), bytes_per_solve=bytes_per_solve))
             B_lm = 1 << 18
             ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv[:B_lm], xyz[:B_lm], K, method="lm12", want_rpy=False),
                                10)

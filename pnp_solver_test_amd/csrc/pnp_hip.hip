@@ -347,7 +347,7 @@ std::atomic<bool> g_rows_staged{getenv("PNP_ROWS_STAGED") != nullptr && getenv("
 // (pnp::OwnRows6): rows in device memory (over the bus the partial cache lines of such loads would
 // be fetched once per load), pixel rows 16-byte aligned, pattern rows aligned to two elements.
 template <typename T>
-bool own_rows_ok(const T *uv, const T *xyz, int64_t xyz_stride, int lpi, int N, bool rows_on_device)
+bool own_rows_ok(const T *uv, const T *xyz, int64_t xyz_stride, int lpi, int N, int64_t B, bool rows_on_device)
 {
     return rows_on_device && lpi == 1 && N == 6 && (xyz_stride == 0 || xyz_stride >= 18) && xyz_stride % 2 == 0 &&
            reinterpret_cast<uintptr_t>(uv) % 16 == 0 && reinterpret_cast<uintptr_t>(xyz) % (2 * sizeof(T)) == 0 &&
@@ -378,8 +378,9 @@ int launch_qeif(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, in
     const int64_t nblk = (B + pb - 1) / pb;
     if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
     const dim3 grid(static_cast<unsigned>(nblk));
-    if (n_patterns == 1 && own_rows_ok(uv, xyz, xyz_stride, lpi, N, rows_on_device)) {
-        hipLaunchKernelGGL((pnp::qeif_rows6_kernel<T>), grid, dim3(block), 0, s, uv, xyz, xyz_stride, ki, B, p, R, t, res,
+    if (n_patterns == 1 && own_rows_ok(uv, xyz, xyz_stride, lpi, N, B, rows_on_device)) {
+        const dim3 rows_grid(static_cast<unsigned>((B + pnp::kRowsBlock - 1) / pnp::kRowsBlock));
+        hipLaunchKernelGGL((pnp::qeif_rows6_kernel<T>), rows_grid, dim3(pnp::kRowsBlock), 0, s, uv, xyz, xyz_stride, ki, B, p, R, t, res,
                            iters, rpy, pid);
         HIP_TRY(hipGetLastError());
         return PNP_OK;
@@ -425,8 +426,9 @@ int launch_dlt(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, con
     const int64_t nblk = (B + pb - 1) / pb;
     if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
     const dim3 grid(static_cast<unsigned>(nblk));
-    if (own_rows_ok(uv, xyz, xyz_stride, lpi, N, rows_on_device)) {
-        hipLaunchKernelGGL((pnp::dlt_rows6_kernel<T>), grid, dim3(block), 0, s, uv, xyz, xyz_stride, ki, B, N, num_it, R,
+    if (own_rows_ok(uv, xyz, xyz_stride, lpi, N, B, rows_on_device)) {
+        const dim3 rows_grid(static_cast<unsigned>((B + pnp::kRowsBlock - 1) / pnp::kRowsBlock));
+        hipLaunchKernelGGL((pnp::dlt_rows6_kernel<T>), rows_grid, dim3(pnp::kRowsBlock), 0, s, uv, xyz, xyz_stride, ki, B, N, num_it, R,
                            t, res, rpy);
         HIP_TRY(hipGetLastError());
         return PNP_OK;

@@ -250,17 +250,22 @@ __global__ __launch_bounds__(kSolveBlock<T>, PNP_QEIF_WAVES) void qeif_kernel(
     }
 }
 
+// Workgroup of the kernels that read their rows themselves: one wavefront.  With no LDS image to
+// share and no barrier, the smallest unit schedules best (1M problems: 0.1576 ms against 0.1587
+// with two wavefronts and 0.1606 with four).
+constexpr int kRowsBlock = 64;
+
 // qeif_kernel<1, 6, T, false> without the LDS image: six points, one lane per problem, one pattern
 // (per problem, xyz_stride >= 18, or shared, xyz_stride == 0), rows in device memory and aligned as
 // OwnRows6 asks.  Same arithmetic on the same values, so the same bits; the launch is shorter by
 // the staging loop, the barrier and the LDS round trip.
 template <typename T>
-__global__ __launch_bounds__(kSolveBlock<T>, PNP_QEIF_WAVES) void qeif_rows6_kernel(
+__global__ __launch_bounds__(kRowsBlock, PNP_QEIF_WAVES) void qeif_rows6_kernel(
     const T *__restrict__ uv, const T *__restrict__ xyz, int64_t xyz_stride, KinvRows ki, int64_t B, QeifParams p,
     T *__restrict__ R_out, T *__restrict__ t_out, T *__restrict__ res_out, int32_t *__restrict__ iters_out,
     T *__restrict__ rpy_out, int32_t *__restrict__ pattern_id_out)
 {
-    const int64_t slot = static_cast<int64_t>(blockIdx.x) * kSolveBlock<T> + threadIdx.x;
+    const int64_t slot = static_cast<int64_t>(blockIdx.x) * kRowsBlock + threadIdx.x;
     const int64_t problem = min(slot, B - 1);  // idle lanes of the last workgroup redo the last problem
     const RegPoints<6> rp(OwnRows6<T>(uv + problem * 12, xyz + problem * xyz_stride, ki));
     double R[9], t[3], res;
@@ -643,11 +648,11 @@ __global__ __launch_bounds__(kSolveBlock<T>, PNP_DLT_WAVES) void dlt_kernel(
 // equations were rank-deficient is solved again through the pseudo-inverse with its points read
 // from memory; N (= 6) comes as an argument so that this rare path stays a loop over the points.
 template <typename T>
-__global__ __launch_bounds__(kSolveBlock<T>, PNP_DLT_WAVES) void dlt_rows6_kernel(
+__global__ __launch_bounds__(kRowsBlock, PNP_DLT_WAVES) void dlt_rows6_kernel(
     const T *__restrict__ uv, const T *__restrict__ xyz, int64_t xyz_stride, KinvRows ki, int64_t B, int N,
     int num_it, T *__restrict__ R_out, T *__restrict__ t_out, T *__restrict__ res_out, T *__restrict__ rpy_out)
 {
-    const int64_t slot = static_cast<int64_t>(blockIdx.x) * kSolveBlock<T> + threadIdx.x;
+    const int64_t slot = static_cast<int64_t>(blockIdx.x) * kRowsBlock + threadIdx.x;
     const int64_t problem = min(slot, B - 1);
     const T *uv_row = uv + problem * 12, *xyz_row = xyz + problem * xyz_stride;
     const RegPoints<6> rp(OwnRows6<T>(uv_row, xyz_row, ki));

@@ -13,7 +13,7 @@ import sys
 
 def main():
     trace, bench_log, out = sys.argv[1:4]
-    prefix = sys.argv[4] if len(sys.argv) > 4 else "void pnp::qeif_kernel<1, 6, float, false>"
+    prefix = sys.argv[4] if len(sys.argv) > 4 else "void pnp::qeif_rows6_kernel<float>"
     line = None
     for text in open(bench_log):
         text = text.strip()

@@ -17,9 +17,9 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", "pmc")
 
 # dispatch order of scripts/pmc_probe.py: 3 launches each
-LAUNCHES = [("qeif_n6_b1m_per_problem_xyz", "qeif_kernel<1, 6,", 1 << 20, 6, True),
-            ("dlt_n6_b1m_per_problem_xyz", "dlt_kernel<1, 6,", 1 << 20, 6, True),
-            ("qeif_n6_b1m_shared_pattern", "qeif_kernel<1, 6,", 1 << 20, 6, False),
+LAUNCHES = [("qeif_n6_b1m_per_problem_xyz", "qeif_rows6_kernel<", 1 << 20, 6, True),
+            ("dlt_n6_b1m_per_problem_xyz", "dlt_rows6_kernel<", 1 << 20, 6, True),
+            ("qeif_n6_b1m_shared_pattern", "qeif_rows6_kernel<", 1 << 20, 6, False),
             ("qeif_n68_b256k_shared_pattern", "qeif_moment_kernel<float, 16, true>", 1 << 18, 68, False),
             ("qeif_n68_b256k_per_problem_xyz", "qeif_moment_lines_kernel<float>", 1 << 18, 68, True)]
 
