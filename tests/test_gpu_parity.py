@@ -1439,6 +1439,65 @@ def test_line_cut_staging_equals_equal_chunk_staging(torch_dev, tmp_path):
         assert np.array_equal(outs["lines"][k], outs["plain"][k]), k
 
 
+def test_row_reading_kernels_equal_the_staged_kernels(golden, torch_dev, tmp_path):
+    """Six-point launches on aligned rows in device memory are solved by lanes that read their own
+    rows; a second process that keeps the LDS-staged kernels (PNP_ROWS_STAGED=1 is read when the
+    library is loaded) must return the same bits: QEIF (with iteration counts, residuals and
+    angles) and DLT through the C ABI, both element types, a pattern per problem, a shared one and
+    pattern rows 26 elements apart, a batch that ends inside a wavefront, and planar patterns,
+    which take the DLT kernels' pseudo-inverse path."""
+    import os
+    import subprocess
+    import sys
+    g, uv = stress_uv6(golden)
+    B = 64 * 37 + 29
+    planar = np.load(os.path.join(os.path.dirname(__file__), "golden", "dlt_planar.npz"))
+    np.savez(tmp_path / "in.npz", uv=uv[:B], P=P6f, uv_planar=planar["uv"], P_planar=planar["xyz"])
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import pnp_solver_test_amd as pnp\n"
+        "from pnp_solver_test_amd import _lib, synth\n"
+        "lib = _lib.load(); d = np.load(%r); out = {}; K = _lib.k_array(synth.K_DEFAULT)\n"
+        "st = torch.cuda.current_stream().cuda_stream\n"
+        "def run(tag, m, uv, xyz, stride):\n"
+        "    B, sfx, dt = uv.shape[0], ('f32' if uv.dtype == torch.float32 else 'f64'), uv.dtype\n"
+        "    R = torch.empty((B, 9), device='cuda', dtype=dt); t = torch.empty((B, 3), device='cuda', dtype=dt)\n"
+        "    res = torch.empty(B, device='cuda', dtype=dt); rpy = torch.empty((B, 3), device='cuda', dtype=dt)\n"
+        "    it = torch.zeros(B, device='cuda', dtype=torch.int32)\n"
+        "    if m == 'qeif':\n"
+        "        rc = getattr(lib, 'pnp_qeif_batch_' + sfx)(uv.data_ptr(), xyz.data_ptr(), stride, K, B, 6, None, R.data_ptr(), t.data_ptr(), res.data_ptr(), it.data_ptr(), rpy.data_ptr(), _lib.PTR_DEVICE, st)\n"
+        "    else:\n"
+        "        rc = getattr(lib, 'pnp_dlt_batch_' + sfx)(uv.data_ptr(), xyz.data_ptr(), stride, K, B, 6, 3, R.data_ptr(), t.data_ptr(), res.data_ptr(), rpy.data_ptr(), _lib.PTR_DEVICE, st)\n"
+        "    _lib.check(rc); torch.cuda.synchronize()\n"
+        "    for k, v in (('R', R), ('t', t), ('res', res), ('rpy', rpy), ('iters', it)):\n"
+        "        out['%%s_%%s_%%s_%%s' %% (sfx, tag, m, k)] = v.cpu().numpy()\n"
+        "uv32 = torch.from_numpy(d['uv']).cuda(); P32 = torch.from_numpy(d['P']).cuda(); B = uv32.shape[0]\n"
+        "wide32 = torch.zeros((B, 26), device='cuda'); wide32[:, :18] = P32.reshape(18)\n"
+        "for dt in (torch.float32, torch.float64):\n"
+        "    uv, own, shared, wide = uv32.to(dt), P32.expand(B, 6, 3).contiguous().to(dt), P32.to(dt).contiguous(), wide32.to(dt)\n"
+        "    up = torch.from_numpy(d['uv_planar']).cuda().to(dt).contiguous(); pp = torch.from_numpy(d['P_planar']).cuda().to(dt).contiguous()\n"
+        "    for m in ('qeif', 'dlt'):\n"
+        "        run('own', m, uv, own, 18); run('shared', m, uv, shared, 0); run('wide', m, uv, wide, 26)\n"
+        "    run('planar', 'dlt', up, pp, 18)\n"
+        "np.savez(sys.argv[1], **out)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "in.npz"))
+    outs = {}
+    for tag, env in (("rows", {}), ("staged", {"PNP_ROWS_STAGED": "1"})):
+        path = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(path)
+    assert sorted(outs["rows"].files) == sorted(outs["staged"].files) and len(outs["rows"].files) == 2 * 7 * 5
+    for k in outs["rows"].files:
+        assert np.array_equal(outs["rows"][k], outs["staged"][k], equal_nan=True), k
+    # ... and the row-reading results are the solver's, not two equal failures
+    ref = solve_dev(uv[:B], P6f, torch_dev)
+    assert np.array_equal(outs["rows"]["f32_own_qeif_R"].reshape(B, 3, 3), ref["R"])
+    assert np.array_equal(outs["rows"]["f32_wide_qeif_t"], ref["t"])
+    assert np.isfinite(outs["rows"]["f64_planar_dlt_R"]).all()
+
+
 def test_moment_form_selection_rules(torch_dev):
     lib = _lib.load()
     assert lib.pnp_get_qeif_form(1 << 18, 68) == _lib.QEIF_FORM_MOMENTS
