@@ -452,6 +452,14 @@ def main():
                 roofline=dict(bound="hbm", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                               frac=round(gbs / HBM_PEAK_GBS, 5), traffic=traffic_of("dlt_n6_b1m_per_problem_xyz_bytes_per_launch"),
                               kernel="pnp::dlt_rows6_kernel<float>", kernel_ms=round(ms, 4), bytes_per_solve=bytes_per_solve))
+            # ... and with the optional residual left out: exactly the 168 bytes (uv, xyz in; R, t out)
+            ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, xyz, K, method="dlt", want_rpy=False, want_res=False),
+                               n_small)
+            gbs = B * bytes_per_solve / (ms * 1e-3) / 1e9
+            other["configs[1]_dlt_n6_b1m_pose_only"] = dict(
+                solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4), achieved_GBps=round(gbs, 1),
+                hbm_frac=round(gbs / HBM_PEAK_GBS, 4),
+                what="res_out = NULL: the kernel skips the residual of its last round (the reference returns it, so the entry above is the drop-in's launch)")
             B_lm = 1 << 18
             ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv[:B_lm], xyz[:B_lm], K, method="lm12", want_rpy=False),
                                10)
