@@ -1367,6 +1367,6 @@ int pnp_max_points(void) { return kMaxPoints; }
 
 const char *pnp_last_error(void) { return g_err; }
 
-const char *pnp_version(void) { return "pnp_hip 0.3 (gfx950)"; }
+const char *pnp_version(void) { return "pnp_hip 0.4 (gfx950)"; }
 
 }  // extern "C"
