@@ -11,6 +11,8 @@
 // small dense algebra redundantly in registers, so no lane ever waits on another.
 // LPI = 64 is one wavefront per problem (latency-optimal for few, large problems);
 // LPI = 1 is one lane per problem (throughput-optimal for millions of six-point problems).
+// Six-point problems with one lane each need no LDS image at all when their rows are aligned and
+// in device memory: qeif_rows6_kernel and dlt_rows6_kernel let every lane read its own rows.
 //
 // All arithmetic is float64.  The problem arrays are float32 (widened on load, results rounded
 // once on store) or float64; the entry points come in both flavours.
