@@ -21,6 +21,11 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                 on the launch stream inside the timed region) against the 8 TB/s HBM peak
   roofline_valu the same launches priced in float64 flops against the vector-FP64 peak, since
                 this kernel is bound by the vector ALU, not by HBM
+  roofline_issue the same launches priced in issue slots: vector instructions per wavefront (from
+                the counter passes) x 4 cycles x wavefronts per SIMD against the cycles of the launch
+The kernel names in the line are what the library says it dispatched (pnp_last_kernel_name), not
+literals; `traffic` comes from the counter passes under profiles/ (traffic_source says which file,
+which commit produced it, and whether it was taken on the kernel that ran here).
   cpu_baseline  the NumPy per-problem restatement of the reference (oracle port) timed on one
                 host core over a bounded sample of the same workload
   other_configs short measurements of the remaining baseline configurations (not the headline)
@@ -44,7 +49,9 @@ BATCH = 1 << 20
 N_POINTS = 6
 
 
-SAMPLE_EVERY = 8     # every 8th timed launch is bracketed by an event pair of its own
+MIN_SAMPLES = 8       # at least this many timed launches carry an event pair of their own
+SIMDS = 1024          # 256 compute units x 4
+ISSUE_CLOCK_GHZ = 2.4 # MI355X peak engine clock: one vector instruction of a wavefront takes 4 cycles of its SIMD's issue port
 SPINUP_MS = 60.0     # every measurement is preceded by at least this much untimed GPU work
 GATHER_DEADLINE_S = 120   # N > 1: the optional result exchange may take this long, then the line goes out without it
 
@@ -88,6 +95,43 @@ def qeif_moment_flops(n_points, iters_mean):
 
 def dlt_flops(n_points, num_it=3):
     return 2.0 * (num_it * (30.0 * n_points + 110.0) + 20.0 * n_points)
+
+
+class CounterTable:
+    """profiles/hbm_traffic.json: what the rocprofv3 --pmc passes measured per launch (HBM bytes,
+    vector instructions per wavefront), with the kernel each row was taken on and the commit the
+    passes ran at.  A row is only handed out for the kernel it was measured on."""
+
+    def __init__(self):
+        self.path = os.path.join("profiles", "hbm_traffic.json")
+        self.table = {}
+        full = os.path.join(ROOT, self.path)
+        if os.path.exists(full):
+            with open(full) as f:
+                self.table = json.load(f)
+
+    def row(self, label, kernel):
+        """(traffic bytes per launch | None, vector instructions per wavefront | None, source dict)"""
+        measured_on = (self.table.get("kernels") or {}).get(label)
+        src = dict(file=self.path, passes=self.table.get("source"), commit=self.table.get("commit"), row=label,
+                   measured_on_kernel=measured_on, this_run_kernel=kernel)
+        if measured_on is not None and kernel and measured_on != kernel:
+            src["note"] = "the counters were taken on another kernel than the one this run dispatched: not reported"
+            return None, None, src
+        return (self.table.get(label + "_bytes_per_launch"), self.table.get(label + "_valu_insts_per_wave"), src)
+
+
+def issue_roofline(insts_per_wave, waves, kernel_ms):
+    """Issue-slot view of a launch: every vector instruction of a wavefront occupies its SIMD's
+    issue port for 4 cycles; achieved = cycles of instruction issue per SIMD, peak = the cycles the
+    launch lasted at the peak engine clock."""
+    if not insts_per_wave:
+        return None
+    issue = insts_per_wave * 4.0 * waves / SIMDS
+    avail = kernel_ms * 1e-3 * ISSUE_CLOCK_GHZ * 1e9
+    return dict(bound="valu_issue", achieved=round(issue), peak=round(avail), unit="cycles per SIMD",
+                frac=round(issue / avail, 4), valu_insts_per_wave=insts_per_wave, wavefronts=waves,
+                clock_GHz=ISSUE_CLOCK_GHZ)
 
 
 def time_launches(torch, fn, steps, warmup=8):
@@ -207,18 +251,25 @@ def launch_ranks(n_ranks, argv):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL needs dmabuf IPC on this driver
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n_ranks,
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    sys.stderr.write(proc.stderr)
     lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
     json_lines = [ln for ln in lines if ln.lstrip().startswith("{") and '"metric"' in ln]
     for ln in lines:
         if ln not in json_lines:
             print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        # the one-line reason a rank gave for leaving (SystemExit messages start with "bench.py:")
+        reasons = [ln.strip() for ln in proc.stderr.splitlines() if ln.strip().startswith("bench.py:")]
+        print("bench.py --gpus %d failed (exit %d): %s" % (n_ranks, proc.returncode,
+                                                           reasons[0][len("bench.py:"):].strip() if reasons else
+                                                           "see the ranks' output above"), file=sys.stderr)
+        return proc.returncode
     if json_lines:
         print(json_lines[-1], flush=True)
-    elif proc.returncode == 0:
-        print("bench.py: the ranks exited without printing a result line", file=sys.stderr)
-        return 1
-    return proc.returncode
+        return 0
+    print("bench.py: the ranks exited without printing a result line", file=sys.stderr)
+    return 1
 
 
 def launcher_check(args):
@@ -289,11 +340,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device; the solver has no CPU path")
+        raise SystemExit("bench.py: no HIP device is visible; the solver has no CPU path")
     if local_rank >= torch.cuda.device_count():
-        raise SystemExit("rank %d wants device %d but only %d are visible" % (rank, local_rank, torch.cuda.device_count()))
+        raise SystemExit("bench.py: rank %d wants device %d but only %d are visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = "RANK" in os.environ          # one of the ranks of torch.distributed.run, any world size
@@ -329,13 +380,15 @@ def main():
     # One HIP event pair on the launch stream around the K launches: its span / K is the mean
     # launch duration, gaps between launches included.  (A pair around every launch puts two
     # markers between consecutive kernels and costs the loop 3 % of wall-clock, so only every
-    # SAMPLE_EVERY-th launch carries a pair of its own, for the minimum and the median.)
+    # sample_every-th launch carries a pair of its own - at least MIN_SAMPLES of them whatever
+    # --steps is - for the minimum and the median.)
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     samples = []
+    sample_every = max(1, args.steps // MIN_SAMPLES)
     t0 = time.perf_counter()
     ev_a.record()
     for i in range(args.steps):
-        if i % SAMPLE_EVERY == SAMPLE_EVERY - 1:
+        if i % sample_every == sample_every - 1:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = step()
@@ -347,13 +400,20 @@ def main():
     enqueue_s = time.perf_counter() - t0        # host time to queue the K launches
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0          # this rank's K steps, start to completion
+    launched = pnp._lib.last_launch()           # what the last of those steps dispatched, from the library
     barrier()                                   # every rank is done; the job's time is the slowest rank's
     kernel_ms = ev_a.elapsed_time(ev_b) / args.steps
     sampled = sorted(a.elapsed_time(b) for a, b in samples)
+    per_rank = None
     if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        mine = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        everyone = torch.empty((world, 2), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(everyone, mine)
+        everyone = everyone.cpu()
+        per_rank = dict(elapsed_ms_per_step=[round(float(v) / args.steps * 1e3, 4) for v in everyone[:, 0]],
+                        kernel_ms=[round(float(v), 4) for v in everyone[:, 1]],
+                        slowest_rank=int(everyone[:, 0].argmax().item()))
+        elapsed = float(everyone[:, 0].max().item())
     iters_mean = float(out["iters"].float().mean().item())
     ok = bool(torch.isfinite(out["R"]).all().item())
 
@@ -364,17 +424,9 @@ def main():
         bytes_per_solve = 20 * N_POINTS + 48
         achieved = B * bytes_per_solve / (kernel_ms * 1e-3) / 1e9
         flops = qeif_flops(N_POINTS, iters_mean)
-        traffic_table = {}
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic_table = json.load(f)
-
-        def traffic_of(key):
-            """HBM bytes per launch from the PMC passes (profiles/hbm_traffic.json), or None."""
-            return traffic_table.get(key)
-
-        traffic = traffic_of("qeif_n6_b1m_bytes_per_launch")
+        counters = CounterTable()
+        traffic, insts, traffic_source = counters.row("qeif_n6_b1m_per_problem_xyz", launched["kernel"])
+        waves = -(-B // 64)
         line = {
             "metric": "PnP solves/sec (N=6, LM 5 iters)",
             "value": round(value, 1),
@@ -411,7 +463,10 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
-                "kernel": "pnp::qeif_rows6_kernel<float>",
+                "traffic_source": traffic_source,
+                "kernel": launched["kernel"],
+                "kernel_source": "pnp_last_kernel_name() after the last timed step",
+                "launch": {k: launched[k] for k in ("grid", "block", "lds_bytes")},
                 "kernel_ms": round(kernel_ms, 4),
                 "kernel_ms_min": round(sampled[0], 4) if sampled else None,
                 "kernel_ms_median": round(sampled[len(sampled) // 2], 4) if sampled else None,
@@ -428,7 +483,11 @@ def main():
                 "frac": round(B * flops / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TF, 4),
                 "flops_per_solve": round(flops, 1),
             },
+            "roofline_issue": issue_roofline(insts, waves, kernel_ms),
+            "library": {"version": pnp.version(), "path": os.path.relpath(pnp._lib.LIB_PATH, ROOT)},
         }
+        if per_rank is not None:
+            line["per_rank"] = per_rank
         if world == 1 and not args.no_other_configs:
             other = {}
             n_small = max(5, min(50, args.steps // 2))
@@ -444,14 +503,20 @@ def main():
             ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, xyz, K, want_rpy=True), n_small)
             other["qeif_n6_with_euler_output"] = dict(solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4))
             ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, xyz, K, method="dlt", want_rpy=False), n_small)
+            ran = pnp._lib.last_launch()
             gbs = B * bytes_per_solve / (ms * 1e-3) / 1e9
+            tr, ins, tsrc = counters.row("dlt_n6_b1m_per_problem_xyz", ran["kernel"])
             other["configs[1]_dlt_n6_b1m"] = dict(
                 solves_per_s=round(B / ms * 1e3, 1), kernel_ms=round(ms, 4),
                 achieved_GBps=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4),
                 valu_fp64_TFLOPs=round(B * dlt_flops(6) / (ms * 1e-3) / 1e12, 2),
                 roofline=dict(bound="hbm", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                              frac=round(gbs / HBM_PEAK_GBS, 5), traffic=traffic_of("dlt_n6_b1m_per_problem_xyz_bytes_per_launch"),
-                              kernel="pnp::dlt_rows6_kernel<float>", kernel_ms=round(ms, 4), bytes_per_solve=bytes_per_solve))
+                              frac=round(gbs / HBM_PEAK_GBS, 5), traffic=tr, traffic_source=tsrc,
+                              kernel=ran["kernel"], launch={k: ran[k] for k in ("grid", "block", "lds_bytes")},
+                              kernel_ms=round(ms, 4), bytes_per_solve=bytes_per_solve),
+                roofline_issue=issue_roofline(ins, waves, ms),
+                achievable_hbm=dict(GBps=6300.0, frac=round(gbs / 6300.0, 4),
+                                    what="against the 6.3 TB/s a streaming read-and-write kernel reaches on this chip"))
             # ... and with the optional residual left out: exactly the 168 bytes (uv, xyz in; R, t out)
             ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv, xyz, K, method="dlt", want_rpy=False, want_res=False),
                                n_small)
@@ -475,18 +540,20 @@ def main():
             own68 = P68d[None].expand(B68, 68, 3).contiguous()
             for tag, xyz68, nbytes in (("shared_pattern", P68d, 8 * 68 + 48), ("per_problem_pattern", own68, 20 * 68 + 48)):
                 ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv68, xyz68, K, want_rpy=False), n_small)
+                ran = pnp._lib.last_launch()
                 gbs = B68 * nbytes / (ms * 1e-3) / 1e9
+                tr, ins, tsrc = counters.row("qeif_n68_b256k_%s" % ("shared_pattern" if tag == "shared_pattern" else "per_problem_xyz"),
+                                             ran["kernel"])
                 other["configs[3]_qeif_n68_b256k_" + tag] = dict(
                     solves_per_s=round(B68 / ms * 1e3, 1), kernel_ms=round(ms, 4), mean_iterations=round(it68, 3),
                     bytes_per_solve=nbytes, achieved_GBps=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4),
                     form="moments" if lib.pnp_get_qeif_form(B68, 68) == pnp._lib.QEIF_FORM_MOMENTS else "points",
                     valu_fp64_TFLOPs=round(B68 * qeif_moment_flops(68, it68) / (ms * 1e-3) / 1e12, 2),
                     roofline=dict(bound="hbm", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                                  frac=round(gbs / HBM_PEAK_GBS, 5),
-                                  traffic=traffic_of("qeif_n68_b256k_%s_bytes_per_launch"
-                                                     % ("shared_pattern" if tag == "shared_pattern" else "per_problem_xyz")),
-                                  kernel="pnp::qeif_moment_kernel<float,16,true>" if tag == "shared_pattern"
-                                  else "pnp::qeif_moment_lines_kernel<float>", kernel_ms=round(ms, 4), bytes_per_solve=nbytes))
+                                  frac=round(gbs / HBM_PEAK_GBS, 5), traffic=tr, traffic_source=tsrc,
+                                  kernel=ran["kernel"], launch={k: ran[k] for k in ("grid", "block", "lds_bytes")},
+                                  kernel_ms=round(ms, 4), bytes_per_solve=nbytes),
+                    roofline_issue=issue_roofline(ins, -(-B68 // 64), ms))
             lib.pnp_set_qeif_form(pnp._lib.QEIF_FORM_POINTS)        # the point-by-point form, for comparison
             try:
                 ms = time_launches(torch, lambda: pnp.solve_pnp_batch(uv68, P68d, K, want_rpy=False), 10)
@@ -528,7 +595,8 @@ def main():
                 pcie_GBps=round(B * (bytes_per_solve + 8) / hs / 1e9, 2),
                 ms_per_call_results_reused=round(hs_reused * 1e3, 3),
                 solves_per_s_results_reused=round(B / hs_reused, 1),
-                what="NumPy arrays in, NumPy arrays out: chunks through page-locked buffers on 8 host threads, kernels launched on those buffers")
+                host_lane_threads=lib.pnp_host_lane_threads(local_rank),
+                what="NumPy arrays in, NumPy arrays out: chunks through page-locked buffers on the library's 8 standing host threads, kernels launched on those buffers")
             # ... and as host tensors in page-locked memory: the kernels work on them over the bus
             uv_p, xyz_p = torch.from_numpy(uv_h).pin_memory(), torch.from_numpy(xyz_h).pin_memory()
 

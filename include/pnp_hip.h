@@ -32,11 +32,14 @@
  *     launched on host memory and read and write it over the bus.  A call all of whose arrays
  *     are page-locked, mapped host memory (hipHostMalloc and the like) is one launch on those
  *     arrays.  Otherwise calls that move 8 MB or more are cut into chunks of up to 4 MB which
- *     eight host threads (seven started by the call, joined before it returns) carry through
- *     page-locked buffers and streams of the library's own: copy a chunk of the pageable arrays
- *     in, launch on the buffer, copy the results out, the lanes overlapping each other; a side
- *     (inputs, outputs) that is page-locked is used as it is.  Results are those of one launch
- *     over the whole batch; work already queued on hip_stream is waited for.
+ *     eight host threads per device carry through page-locked buffers and streams of the
+ *     library's own: copy a chunk of the pageable arrays in, launch on the buffer, copy the
+ *     results out, the threads overlapping each other; a side (inputs, outputs) that is
+ *     page-locked is used as it is.  The threads are started by the first such call on a device
+ *     (none exists before it) and stay, waiting, until the library is unloaded; concurrent
+ *     callers share them chunk by chunk.  Results are those of one launch over the whole batch;
+ *     work already queued on hip_stream is waited for.
+ *   - The library reads no environment variable.
  */
 #ifndef PNP_HIP_H
 #define PNP_HIP_H
@@ -126,7 +129,10 @@ int pnp_lm12_batch_f32(const float *uv, const float *xyz, int64_t xyz_problem_st
  * them to and from a static device array of PNP_NOALLOC_SCRATCH_BYTES bytes that every GPU the library runs on holds for
  * the life of the process.  It calls no hipMalloc, hipFree or hipHostMalloc.
  *   - Arguments and results are exactly those of pnp_qeif_batch_f32 with ptr_kind = PNP_PTR_HOST
- *     (same kernels, bit-identical outputs); xyz_problem_stride is 0 or 3*N.
+ *     (bit-identical outputs); xyz_problem_stride is 0 or 3*N.  The kernels work on the static
+ *     device array, so six-point problems may run the kernel whose lanes read their own rows
+ *     where the host-pointer path, whose kernels read host memory, runs the LDS-staged one: the
+ *     two return the same bits.
  *   - Limit: the staged arrays - B*(8N [+ 12N with per-problem xyz] + 68) bytes plus the shared
  *     pattern, each of eight pieces padded to 256 bytes - must fit the static array; a larger
  *     call fails with PNP_E_ARG and names the largest B that fits (about 89 000 six-point
@@ -252,8 +258,12 @@ int pnp_gather_results(const void *send, void *recv, int64_t bytes_per_rank, int
                        int32_t rank, int32_t world, void *comm, void *hip_stream);
 
 /* How many lanes of a wavefront cooperate on one problem: 1, 2, 4, 8, 16, 32 or 64
- * (64 = one wavefront per problem); 0 restores the automatic choice from (B, N).
- * Process-wide; meant for tuning and tests.  No reference counterpart. */
+ * (64 = one wavefront per problem); 0 restores the automatic choice from (B, N).  The automatic
+ * choice keeps a workgroup's staged points within 48 KB of LDS; a forced count may go down to
+ * what 160 KB hold (one workgroup per compute unit).
+ * Belongs to the calling thread: it changes that thread's launches only (a host-pointer call
+ * carries it to the library's own threads).  Meant for tuning and tests.  No reference
+ * counterpart. */
 int pnp_set_lanes_per_problem(int32_t lanes);
 
 /* Which arithmetic form the QEIF entry points run.  Both follow the same recurrence and agree
@@ -263,17 +273,30 @@ int pnp_set_lanes_per_problem(int32_t lanes);
  *                          about 700 fused operations whatever N is; one lane per problem
  *   PNP_QEIF_FORM_AUTO     moments when N >= 10, B >= 2048, one pattern and no forced lane
  *                          count; points otherwise (the default)
- * Process-wide; meant for tuning and tests.  No reference counterpart. */
+ * Belongs to the calling thread, like pnp_set_lanes_per_problem.  No reference counterpart. */
 #define PNP_QEIF_FORM_AUTO 0
 #define PNP_QEIF_FORM_POINTS 1
 #define PNP_QEIF_FORM_MOMENTS 2
 int pnp_set_qeif_form(int32_t form);
 
-/* The form (POINTS or MOMENTS) the next single-pattern QEIF launch would use for (B, N). */
+/* The form (POINTS or MOMENTS) the calling thread's next single-pattern QEIF launch would use
+ * for (B, N). */
 int pnp_get_qeif_form(int64_t B, int32_t N);
 
 /* The value the next float32 launch would use for (B, N). */
 int pnp_get_lanes_per_problem(int64_t B, int32_t N, int64_t xyz_problem_stride);
+
+/* The kernel the calling thread's last solver launch dispatched, by the name a profiler shows
+ * for it without the argument list (e.g. "pnp::qeif_rows6_kernel<float>"), "" before the first
+ * launch; for a chunked host-pointer call, the kernel of its chunks.  pnp_last_launch gives that
+ * launch's geometry: workgroups, threads per workgroup, bytes of dynamic LDS (each pointer may
+ * be NULL).  No reference counterpart: measurement harnesses use it to name what they timed. */
+const char *pnp_last_kernel_name(void);
+void pnp_last_launch(int64_t *grid, int32_t *block, int32_t *lds_bytes);
+
+/* Number of host threads the library keeps for chunked host-pointer calls on `device`: 0 until
+ * the first such call, 8 afterwards. */
+int pnp_host_lane_threads(int device);
 
 /* Largest N accepted by the solvers. */
 int pnp_max_points(void);

@@ -36,7 +36,8 @@ EXPORTS = (
     "pnp_qeif_batch_f64", "pnp_dlt_batch_f64", "pnp_lm12_batch_f64", "pnp_euler_deg_f64",
     "pnp_qeif_multi_batch_f64", "pnp_project_batch_f64", "pnp_compare_batch_f32", "pnp_compare_batch_f64",
     "pnp_set_lanes_per_problem", "pnp_get_lanes_per_problem", "pnp_set_qeif_form", "pnp_get_qeif_form",
-    "pnp_max_points", "pnp_qeif_batch_noalloc_f32",
+    "pnp_max_points", "pnp_qeif_batch_noalloc_f32", "pnp_last_kernel_name", "pnp_last_launch",
+    "pnp_host_lane_threads",
     "pnp_comm_unique_id", "pnp_comm_init", "pnp_comm_destroy", "pnp_gather_results",
     "pnp_last_error", "pnp_version",
 )
@@ -112,6 +113,12 @@ def load():
     lib.pnp_get_lanes_per_problem.restype = ctypes.c_int
     lib.pnp_max_points.argtypes = []
     lib.pnp_max_points.restype = ctypes.c_int
+    lib.pnp_last_kernel_name.argtypes = []
+    lib.pnp_last_kernel_name.restype = ctypes.c_char_p
+    lib.pnp_last_launch.argtypes = [ctypes.POINTER(i64), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    lib.pnp_last_launch.restype = None
+    lib.pnp_host_lane_threads.argtypes = [ctypes.c_int]
+    lib.pnp_host_lane_threads.restype = ctypes.c_int
     lib.pnp_last_error.argtypes = []
     lib.pnp_last_error.restype = ctypes.c_char_p
     lib.pnp_version.argtypes = []
@@ -123,6 +130,15 @@ def load():
 def check(rc: int) -> None:
     if rc < 0:
         raise PnpError("libpnp_hip: %s (code %d)" % (load().pnp_last_error().decode(), rc))
+
+
+def last_launch() -> dict:
+    """What the calling thread's last solver launch was: kernel name as a profiler shows it, and
+    grid / block / dynamic LDS (pnp_last_kernel_name, pnp_last_launch)."""
+    lib = load()
+    g, b, l = ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32()
+    lib.pnp_last_launch(ctypes.byref(g), ctypes.byref(b), ctypes.byref(l))
+    return dict(kernel=lib.pnp_last_kernel_name().decode(), grid=g.value, block=b.value, lds_bytes=l.value)
 
 
 def default_params() -> QeifParams:

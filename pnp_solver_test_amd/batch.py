@@ -87,7 +87,10 @@ def solve_pnp_batch(uv, xyz, K, *, method="qeif", params=None, num_it=None, want
     Returns a dict: R (B,3,3), t (B,3), t3 (B,), res_norm (B,), rpy_deg (B,3) = roll, yaw, pitch
     in the reference's tuple order (if want_rpy), iters (B,) int32 (QEIF only).  Arrays are of
     the same kind as `uv`: NumPy, torch on the same device, or - for a host tensor in pinned
-    memory - pinned host tensors (no copies then: the kernels work on that memory over the bus).
+    memory - pinned host tensors (no copies then: the kernels work on that memory over the bus; a
+    pinned view that is not contiguous is copied to pinned memory first).  Without `out=` every
+    call allocates its result arrays - for pinned host tensors that is one hipHostMalloc per array
+    and call - so repeated calls, pinned ones above all, should pass `out=`.
     """
     if method not in METHODS:
         raise ValueError("method must be one of %s" % (METHODS,))
@@ -179,6 +182,12 @@ def _solve_torch(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, f
         raise ValueError("uv and xyz must be on the same device")
     uv = uv.contiguous()
     src = src.contiguous()
+    if on_host:
+        # .contiguous() of a pinned view that is not contiguous hands back a pageable copy, which
+        # would send the call down the chunked path: pin the copy, so that what was promised for
+        # pinned input (kernels working on that memory, no staging) holds for views as well
+        uv = uv if uv.is_pinned() else uv.pin_memory()
+        src = src if src.is_pinned() else src.pin_memory()
     if patterns is not None:
         if src.dim() != 3 or tuple(src.shape[1:]) != (uv.shape[1], 3):
             raise ValueError("patterns must have shape (P, N, 3)")

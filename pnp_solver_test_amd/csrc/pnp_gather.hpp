@@ -7,24 +7,58 @@
 
 #include <dlfcn.h>
 
+#include <type_traits>
+
+// Where rccl.h is installed (pnp_hip.hip includes it at file scope and defines PNP_HAVE_RCCL_H) the
+// table below is typed with its own typedefs and every entry is checked, at compile time, against
+// the prototype the header declares (argument order and types); nothing of RCCL is linked either
+// way.  Without the header the same table is typed by hand: ncclResult_t and ncclDataType_t are
+// int-sized enums (0 = success, ncclChar = 0), ncclComm_t an opaque pointer, ncclUniqueId 128
+// opaque bytes passed by value.
 struct Rccl {
-    // the subset of rccl.h this file calls (ncclResult_t is an int-sized enum, 0 = success;
-    // ncclComm_t an opaque pointer; ncclUniqueId 128 opaque bytes passed by value; ncclChar = 0)
+#ifdef PNP_HAVE_RCCL_H
+    using UniqueId = ncclUniqueId;
+    using Result = ncclResult_t;
+    using Comm = ncclComm_t;
+    using DataType = ncclDataType_t;
+    static constexpr DataType kChar = ncclChar;
+#else
     struct UniqueId {
         char internal[128];
     };
-    int (*GetUniqueId)(UniqueId *) = nullptr;
-    int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
-    int (*CommDestroy)(void *) = nullptr;
-    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
-    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
+    using Result = int;
+    using Comm = void *;
+    using DataType = int;
+    static constexpr DataType kChar = 0;
+#endif
+    Result (*GetUniqueId)(UniqueId *) = nullptr;
+    Result (*CommInitRank)(Comm *, int, UniqueId, int) = nullptr;
+    Result (*CommDestroy)(Comm) = nullptr;
+    Result (*AllGather)(const void *, void *, size_t, DataType, Comm, hipStream_t) = nullptr;
+    Result (*Send)(const void *, size_t, DataType, int, Comm, hipStream_t) = nullptr;
+    Result (*Recv)(void *, size_t, DataType, int, Comm, hipStream_t) = nullptr;
+    Result (*GroupStart)() = nullptr;
+    Result (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(Result) = nullptr;
     bool ok = false;
     char why[256] = "";
 };
+
+static_assert(sizeof(Rccl::UniqueId) == PNP_COMM_ID_BYTES, "PNP_COMM_ID_BYTES must be the size of ncclUniqueId");
+static_assert(sizeof(Rccl::Result) == sizeof(int) && sizeof(Rccl::DataType) == sizeof(int) &&
+                  sizeof(Rccl::Comm) == sizeof(void *) && static_cast<int>(Rccl::kChar) == 0,
+              "the C ABI passes RCCL's status as int, its communicator as void * and counts bytes as ncclChar");
+#ifdef PNP_HAVE_RCCL_H
+static_assert(std::is_same<decltype(&ncclGetUniqueId), decltype(Rccl::GetUniqueId)>::value, "ncclGetUniqueId");
+static_assert(std::is_same<decltype(&ncclCommInitRank), decltype(Rccl::CommInitRank)>::value, "ncclCommInitRank");
+static_assert(std::is_same<decltype(&ncclCommDestroy), decltype(Rccl::CommDestroy)>::value, "ncclCommDestroy");
+static_assert(std::is_same<decltype(&ncclAllGather), decltype(Rccl::AllGather)>::value, "ncclAllGather");
+static_assert(std::is_same<decltype(&ncclSend), decltype(Rccl::Send)>::value, "ncclSend");
+static_assert(std::is_same<decltype(&ncclRecv), decltype(Rccl::Recv)>::value, "ncclRecv");
+static_assert(std::is_same<decltype(&ncclGroupStart), decltype(Rccl::GroupStart)>::value, "ncclGroupStart");
+static_assert(std::is_same<decltype(&ncclGroupEnd), decltype(Rccl::GroupEnd)>::value, "ncclGroupEnd");
+static_assert(std::is_same<decltype(&ncclGetErrorString), decltype(Rccl::GetErrorString)>::value, "ncclGetErrorString");
+#endif
 
 // Opens RCCL once per process.  A copy already mapped into the process (PyTorch-ROCm brings its
 // own) is the one found, since the lookup is by soname.
@@ -67,7 +101,7 @@ inline const Rccl &rccl()
 
 #define RCCL_TRY(expr)                                                                                    \
     do {                                                                                                  \
-        const int e_ = (expr);                                                                            \
+        const Rccl::Result e_ = (expr);                                                                   \
         if (e_ != 0) return fail(PNP_E_RCCL, "%s failed: %s", #expr, rccl().GetErrorString(e_));          \
     } while (0)
 
@@ -98,7 +132,7 @@ inline int comm_init_impl(const void *id_in, int32_t rank, int32_t world, void *
     if (rc) return rc;
     Rccl::UniqueId id;
     std::memcpy(id.internal, id_in, sizeof id.internal);
-    void *comm = nullptr;
+    Rccl::Comm comm = nullptr;
     RCCL_TRY(rccl().CommInitRank(&comm, world, id, rank));
     *comm_out = comm;
     return PNP_OK;
@@ -110,7 +144,7 @@ inline int comm_destroy_impl(void *comm)
     if (!comm) return PNP_OK;
     int rc = rccl_ready();
     if (rc) return rc;
-    RCCL_TRY(rccl().CommDestroy(comm));
+    RCCL_TRY(rccl().CommDestroy(static_cast<Rccl::Comm>(comm)));
     return PNP_OK;
 }
 
@@ -119,8 +153,9 @@ inline int comm_destroy_impl(void *comm)
 // ranks' slices travel over world - 1 different xGMI links into one device, the root copies its
 // own slice on the device).
 inline int gather_impl(const void *send, void *recv, int64_t bytes_per_rank, int32_t root, int32_t rank, int32_t world,
-                       void *comm, hipStream_t s)
+                       void *comm_handle, hipStream_t s)
 {
+    const Rccl::Comm comm = static_cast<Rccl::Comm>(comm_handle);
     g_err[0] = 0;
     if (bytes_per_rank < 0) return fail(PNP_E_ARG, "bytes_per_rank = %lld is negative", static_cast<long long>(bytes_per_rank));
     if (world < 1 || rank < 0 || rank >= world) return fail(PNP_E_ARG, "rank %d outside [0, %d)", rank, world);
@@ -133,21 +168,21 @@ inline int gather_impl(const void *send, void *recv, int64_t bytes_per_rank, int
     if (rc) return rc;
     const size_t n = static_cast<size_t>(bytes_per_rank);
     if (root < 0) {
-        RCCL_TRY(rccl().AllGather(send, recv, n, /*ncclChar*/ 0, comm, s));
+        RCCL_TRY(rccl().AllGather(send, recv, n, Rccl::kChar, comm, s));
         return PNP_OK;
     }
     RCCL_TRY(rccl().GroupStart());
     if (rank == root) {
         for (int r = 0; r < world; ++r) {
             if (r == rank) continue;
-            const int e = rccl().Recv(static_cast<char *>(recv) + n * r, n, 0, r, comm, s);
+            const Rccl::Result e = rccl().Recv(static_cast<char *>(recv) + n * r, n, Rccl::kChar, r, comm, s);
             if (e != 0) {
                 (void)rccl().GroupEnd();
                 return fail(PNP_E_RCCL, "ncclRecv from rank %d failed: %s", r, rccl().GetErrorString(e));
             }
         }
     } else {
-        const int e = rccl().Send(send, n, 0, root, comm, s);
+        const Rccl::Result e = rccl().Send(send, n, Rccl::kChar, root, comm, s);
         if (e != 0) {
             (void)rccl().GroupEnd();
             return fail(PNP_E_RCCL, "ncclSend to rank %d failed: %s", root, rccl().GetErrorString(e));

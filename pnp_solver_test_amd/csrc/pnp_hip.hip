@@ -10,6 +10,9 @@
 #include <string.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -23,6 +26,15 @@
 
 #include "pnp_kernels.hpp"
 
+// RCCL's header, where there is one: only its types and prototypes are used (pnp_gather.hpp checks
+// its own table against them); the library itself is opened at run time.
+#if defined(__has_include)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#define PNP_HAVE_RCCL_H 1
+#endif
+#endif
+
 // Staging memory of pnp_qeif_batch_noalloc_f32, the entry point that allocates nothing: every
 // device the library's code object is loaded on holds its own copy of this array until the
 // process ends.  In host code the name is only a handle for hipGetSymbolAddress; the device
@@ -34,7 +46,14 @@ namespace {
 using pnp::kBlock;
 
 constexpr int kMaxPoints = 512;          // LPI = 64 keeps 4 problems x 20 B x 512 points in LDS
-constexpr int kLdsBudget = 48 * 1024;    // bytes of dynamic LDS a launch may ask for
+// Dynamic LDS of a point-form launch.  A workgroup's correspondences must fit it, which sets the
+// smallest number of lanes per problem.  The automatic choice stays within kLdsAuto, which leaves
+// room for three workgroups on a compute unit's 160 KB; a forced lane count (pnp_set_lanes_per_problem)
+// may take up to kLdsMax, one workgroup per compute unit, which a kernel has to be allowed first
+// (allow_lds).
+constexpr size_t kLdsAuto = 48 * 1024;
+constexpr size_t kLdsPlain = 64 * 1024;   // what a kernel may take without being allowed more
+constexpr size_t kLdsMax = 160 * 1024;
 constexpr int kMaxDevices = 64;
 
 thread_local char g_err[512] = "";
@@ -56,8 +75,40 @@ int fail(int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                                \
     } while (0)
 
-std::atomic<int> g_forced_lpi{0};
-std::atomic<int> g_qeif_form{PNP_QEIF_FORM_AUTO};
+// Tuning overrides (pnp_set_lanes_per_problem, pnp_set_qeif_form) belong to the thread that set
+// them: they change that thread's launches and nobody else's.  A host-pointer call that hands
+// chunks to the library's lane threads passes its caller's values along with them.
+struct Tuning {
+    int forced_lpi = 0;
+    int qeif_form = PNP_QEIF_FORM_AUTO;
+};
+thread_local Tuning g_tuning;
+
+// What the calling thread's last solver launch was: the kernel by the name a profiler shows for it,
+// and its geometry.  Filled by the launchers; read by pnp_last_kernel_name / pnp_last_launch.
+struct LaunchRecord {
+    char kernel[128] = "";
+    int64_t grid = 0;
+    int32_t block = 0, lds = 0;
+};
+thread_local LaunchRecord g_last_launch;
+
+template <typename T>
+constexpr const char *elem_name()
+{
+    return sizeof(T) == 4 ? "float" : "double";
+}
+
+void note_launch(int64_t grid, int block, size_t lds, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_launch.kernel, sizeof g_last_launch.kernel, fmt, ap);
+    va_end(ap);
+    g_last_launch.grid = grid;
+    g_last_launch.block = block;
+    g_last_launch.lds = static_cast<int32_t>(lds);
+}
 
 // The moment form pays once an iteration's fixed cost (~700 fused operations) is below the
 // point-by-point 78 N: measured crossover between N = 8 and N = 10 at half a million problems.
@@ -68,17 +119,17 @@ constexpr int64_t kMomentMinBatch = 2048;
 
 // ---- per-device staging for host-pointer calls -------------------------------------------
 
-// Large host-pointer calls are cut into chunks that kPipeLanes host threads carry side by side,
-// each with a stream and a page-locked buffer of its own.  A lane copies a chunk from the caller's
-// (pageable) arrays into its buffer, launches the solver on the device address of that buffer -
-// the kernels read the inputs and write the results over the bus, there are no copy operations and
-// no device-side staging - waits, and copies the results out to the caller's arrays; a side of the
-// call (inputs, outputs) whose arrays are page-locked already is handed to the kernels as it is.
+// Large host-pointer calls are cut into chunks that kPipeLanes host threads ("lanes") carry side
+// by side, each with a stream and a page-locked buffer of its own.  A lane copies a chunk from the
+// caller's (pageable) arrays into its buffer, launches the solver on the device address of that
+// buffer - the kernels read the inputs and write the results over the bus, there are no copy
+// operations and no device-side staging - waits, and copies the results out to the caller's arrays;
+// a side of the call (inputs, outputs) whose arrays are page-locked already is handed to the kernels
+// as it is.  The lanes of a device are threads that stay: the first call large enough to be chunked
+// starts them, later calls find them waiting, and the chunks of two callers share them (and the bus)
+// chunk by chunk.  They end when the library is unloaded or the process exits.
 // Measured on the pool's hosts: one thread copies pageable -> page-locked memory at 23 GB/s, eight
 // at 80 GB/s; page-locked memory crosses the bus at 57 GB/s in either direction, both at once.
-// 1M six-point problems with a pattern each: 3.5-3.8 ms with 8 lanes and 4 MB chunks, against 4.5
-// ms with four lanes that copied each chunk to device memory and back (2 + 6 copy operations per
-// chunk), 10.6 ms without chunks.
 #ifndef PNP_PIPE_LANES
 #define PNP_PIPE_LANES 8
 #endif
@@ -94,8 +145,67 @@ constexpr size_t kPipeMinBytes = size_t(PNP_PIPE_MIN_MB) << 20;    // calls movi
 
 struct PipeLane {
     hipStream_t stream = nullptr;
-    void *pinned = nullptr;
+    void *pinned = nullptr;      // page-locked buffer of the chunk in hand (grow-only)
+    void *pinned_dev = nullptr;  // its device address
     size_t pinned_cap = 0;
+    void *pattern = nullptr;     // device copy of the shared pattern(s) of the call in hand (grow-only)
+    size_t pattern_cap = 0;
+    uint64_t pattern_of = 0;     // the call whose pattern it holds
+};
+
+// The lane threads of one device and the queue of chunks they work off.
+struct LanePool {
+    std::mutex mu;
+    std::condition_variable wake;
+    std::deque<std::function<void(PipeLane &)>> chunks;
+    std::vector<std::thread> threads;
+    PipeLane lane[kPipeLanes];
+    bool stop = false;
+
+    // Starts the lane threads of device `dev` if they are not running; caller does not hold mu.
+    int ensure_started(int dev)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!threads.empty()) return PNP_OK;
+        try {
+            threads.reserve(kPipeLanes);
+            for (int l = 0; l < kPipeLanes; ++l) threads.emplace_back(&LanePool::run, this, dev, l);
+        } catch (...) {
+            // fewer lanes than asked for still carry every chunk; none at all is an error
+        }
+        if (threads.empty()) return fail(PNP_E_HIP, "no thread could be started for the host-pointer pipeline");
+        return PNP_OK;
+    }
+
+    void run(int dev, int l)
+    {
+        (void)hipSetDevice(dev);
+        PipeLane &ln = lane[l];
+        for (;;) {
+            std::function<void(PipeLane &)> job;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                wake.wait(lock, [&] { return stop || !chunks.empty(); });
+                if (chunks.empty()) return;   // stop, and nothing left to carry
+                job = std::move(chunks.front());
+                chunks.pop_front();
+            }
+            job(ln);
+        }
+    }
+
+    // The threads are joined before the process image goes away; the buffers and streams are left
+    // to the runtime, which may already be shutting down by then.
+    ~LanePool()
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            stop = true;
+        }
+        wake.notify_all();
+        for (auto &t : threads)
+            if (t.joinable()) t.join();
+    }
 };
 
 struct Staging {
@@ -105,13 +215,13 @@ struct Staging {
     void *pinned = nullptr;  // page-locked host memory for calls below the chunking threshold (grow-only)
     void *pinned_dev = nullptr;  // its device address
     size_t pinned_cap = 0;
-    PipeLane lane[kPipeLanes];
-    hipEvent_t entry = nullptr;  // marks the caller's stream at the start of a pipelined call
 };
 
 // Smallest size of the page-locked buffer that calls below the chunking threshold go through.
 constexpr size_t kSmallCall = 256 * 1024;
 Staging g_staging[kMaxDevices];
+LanePool g_lanes[kMaxDevices];
+std::atomic<uint64_t> g_call_serial{0};
 
 // Grow-only device buffer of the current device; caller holds st.mu.
 int staging_reserve(Staging &st, size_t bytes)
@@ -198,15 +308,36 @@ size_t lds_bytes(int lpi, int N, bool per_problem_xyz, int n_patterns, size_t el
     return (uv + xyz) * elem;
 }
 
+// Lets kernel `fn` take `lds` bytes of dynamic LDS on the current device when that is more than a
+// kernel may take unasked; remembered per (device, kernel).
+int allow_lds(const void *fn, size_t lds)
+{
+    if (lds <= kLdsPlain) return PNP_OK;
+    if (lds > kLdsMax) return fail(PNP_E_ARG, "%zu bytes of LDS per workgroup exceed the %zu a compute unit has", lds, kLdsMax);
+    static std::mutex mu;
+    static std::vector<std::pair<int, const void *>> done;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto &d : done)
+        if (d.first == dev && d.second == fn) return PNP_OK;
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
+    done.emplace_back(dev, fn);
+    return PNP_OK;
+}
+
 // Lanes per problem.  The floor is set by LDS: a workgroup's correspondences must fit the
 // budget.  Above the floor, more lanes per problem only pay when the batch is too small to
 // give every lane of the chip its own problem.
 int choose_lpi(int64_t B, int N, bool per_problem_xyz, int n_patterns, size_t elem)
 {
-    int forced = g_forced_lpi.load();
+    const int forced = g_tuning.forced_lpi;
     int lpi = 1;
-    while (lpi < 64 && lds_bytes(lpi, N, per_problem_xyz, n_patterns, elem) > kLdsBudget) lpi *= 2;
-    if (forced > 0) return forced > lpi ? forced : lpi;
+    if (forced > 0) {
+        while (lpi < 64 && lds_bytes(lpi, N, per_problem_xyz, n_patterns, elem) > kLdsMax) lpi *= 2;
+        return forced > lpi ? forced : lpi;
+    }
+    while (lpi < 64 && lds_bytes(lpi, N, per_problem_xyz, n_patterns, elem) > kLdsAuto) lpi *= 2;
     const int64_t chip_lanes = 256LL * 64 * 8;  // CUs x wave width x resident waves aimed for
     while (lpi < 64 && 2 * lpi <= N && B * lpi * 2 <= chip_lanes) lpi *= 2;
     return lpi;
@@ -258,18 +389,32 @@ pnp::QeifParams to_device_params(const pnp_qeif_params *p)
 
 // ---- launchers (device pointers only; T = element type of the problem arrays) ----------------
 
-// Experiment switch (environment PNP_MOMENT_PLAIN=1): per-problem patterns through the equal-chunk
-// moment kernel instead of the line-cut one.
-std::atomic<bool> g_moment_plain{getenv("PNP_MOMENT_PLAIN") != nullptr && getenv("PNP_MOMENT_PLAIN")[0] == '1'};
+// A/B switches, present only in a build with -DPNP_AB_SWITCHES (libpnp_hip_ab.so, which the tests
+// and timing scripts that compare kernel variants load): PNP_MOMENT_PLAIN=1 in the environment sends
+// per-problem patterns through the equal-chunk moment kernel instead of the line-cut one, and
+// PNP_ROWS_STAGED=1 six-point launches through the LDS-staged kernels even where every lane could
+// read its own rows.  The library proper reads no environment variable.
+#ifdef PNP_AB_SWITCHES
+bool env_is_1(const char *name)
+{
+    const char *v = getenv(name);
+    return v != nullptr && v[0] == '1';
+}
+const bool g_moment_plain = env_is_1("PNP_MOMENT_PLAIN");
+const bool g_rows_staged = env_is_1("PNP_ROWS_STAGED");
+#else
+constexpr bool g_moment_plain = false;
+constexpr bool g_rows_staged = false;
+#endif
 
 // True when a QEIF launch should run in moment form.
 bool use_moment_form(int64_t B, int N, int n_patterns)
 {
     if (n_patterns != 1) return false;
-    const int form = g_qeif_form.load();
+    const int form = g_tuning.qeif_form;
     if (form == PNP_QEIF_FORM_POINTS) return false;
     if (form == PNP_QEIF_FORM_MOMENTS) return true;
-    return g_forced_lpi.load() == 0 && N >= kMomentMinPoints && B >= kMomentMinBatch;
+    return g_tuning.forced_lpi == 0 && N >= kMomentMinPoints && B >= kMomentMinBatch;
 }
 
 // LDS of qeif_moment_lines_kernel<T>: more than a kernel may take without being allowed to, which
@@ -312,12 +457,15 @@ int launch_qeif_moment(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_str
         const size_t pat = static_cast<size_t>(9) * N * sizeof(double);
         const size_t lds_long = ((2 * c_shared * row * sizeof(T) + 7) & ~static_cast<size_t>(7)) + pat;
         const size_t lds_short = ((2 * c_own * row * sizeof(T) + 7) & ~static_cast<size_t>(7)) + pat;
-        if (lds_long <= 64 * 1024)
+        if (lds_long <= kLdsPlain) {
             hipLaunchKernelGGL((pnp::qeif_moment_kernel<T, c_shared, true>), grid, dim3(block), lds_long, s, uv, xyz,
                                xyz_stride, ki, B, N, p, R, t, res, iters, rpy);
-        else
+            note_launch(nblk, block, lds_long, "pnp::qeif_moment_kernel<%s, %d, true>", elem_name<T>(), c_shared);
+        } else {
             hipLaunchKernelGGL((pnp::qeif_moment_kernel<T, c_own, true>), grid, dim3(block), lds_short, s, uv, xyz,
                                xyz_stride, ki, B, N, p, R, t, res, iters, rpy);
+            note_launch(nblk, block, lds_short, "pnp::qeif_moment_kernel<%s, %d, true>", elem_name<T>(), c_own);
+        }
     } else {
         // chunks cut at the cache lines: all of a CU's LDS between two workgroups
         constexpr size_t lines_lds = lines_kernel_lds<T>();
@@ -326,22 +474,20 @@ int launch_qeif_moment(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_str
         const bool offsets_fit = static_cast<uint64_t>(block) * static_cast<uint64_t>(xyz_stride) * sizeof(T) < (uint64_t(1) << 31);
         // measured on 256k-512k problems: ahead from about 24 float32 (12 float64) points per problem
         const bool long_rows = static_cast<size_t>(N) * sizeof(T) >= 96;
-        if (lines_ready && offsets_fit && long_rows && !g_moment_plain.load()) {
+        if (lines_ready && offsets_fit && long_rows && !g_moment_plain) {
             hipLaunchKernelGGL((pnp::qeif_moment_lines_kernel<T>), grid, dim3(block), lines_lds, s, uv, xyz, xyz_stride, ki,
                                B, N, p, R, t, res, iters, rpy);
+            note_launch(nblk, block, lines_lds, "pnp::qeif_moment_lines_kernel<%s>", elem_name<T>());
         } else {
             const size_t lds = 5 * c_own * row * sizeof(T);
             hipLaunchKernelGGL((pnp::qeif_moment_kernel<T, c_own, false>), grid, dim3(block), lds, s, uv, xyz,
                                xyz_stride, ki, B, N, p, R, t, res, iters, rpy);
+            note_launch(nblk, block, lds, "pnp::qeif_moment_kernel<%s, %d, false>", elem_name<T>(), c_own);
         }
     }
     HIP_TRY(hipGetLastError());
     return PNP_OK;
 }
-
-// Experiment switch (environment PNP_ROWS_STAGED=1): six-point launches through the LDS-staged
-// kernels even where every lane could read its own rows.
-std::atomic<bool> g_rows_staged{getenv("PNP_ROWS_STAGED") != nullptr && getenv("PNP_ROWS_STAGED")[0] == '1'};
 
 // True when the lanes of a six-point, one-lane-per-problem launch may read their rows themselves
 // (pnp::OwnRows6): rows in device memory (over the bus the partial cache lines of such loads would
@@ -351,7 +497,7 @@ bool own_rows_ok(const T *uv, const T *xyz, int64_t xyz_stride, int lpi, int N, 
 {
     return rows_on_device && lpi == 1 && N == 6 && (xyz_stride == 0 || xyz_stride >= 18) && xyz_stride % 2 == 0 &&
            reinterpret_cast<uintptr_t>(uv) % 16 == 0 && reinterpret_cast<uintptr_t>(xyz) % (2 * sizeof(T)) == 0 &&
-           !g_rows_staged.load();
+           !g_rows_staged;
 }
 
 template <typename T>
@@ -370,29 +516,38 @@ int launch_qeif(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, in
     }
     const int lpi = choose_lpi(plan_B, N, xyz_stride != 0, n_patterns, sizeof(T));
     const size_t lds = lds_bytes(lpi, N, xyz_stride != 0, n_patterns, sizeof(T));
-    if (lds > 64 * 1024)
-        return fail(PNP_E_ARG, "N = %d with %d pattern(s) needs %zu bytes of LDS per workgroup (max 65536)",
-                    N, n_patterns, lds);
+    if (lds > kLdsMax)
+        return fail(PNP_E_ARG, "N = %d with %d pattern(s) needs %zu bytes of LDS per workgroup (max %zu)",
+                    N, n_patterns, lds, kLdsMax);
     constexpr int block = pnp::kSolveBlock<T>;
     const int64_t pb = block / lpi;
     const int64_t nblk = (B + pb - 1) / pb;
     if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
     const dim3 grid(static_cast<unsigned>(nblk));
     if (n_patterns == 1 && own_rows_ok(uv, xyz, xyz_stride, lpi, N, B, rows_on_device)) {
-        const dim3 rows_grid(static_cast<unsigned>((B + pnp::kRowsBlock - 1) / pnp::kRowsBlock));
-        hipLaunchKernelGGL((pnp::qeif_rows6_kernel<T>), rows_grid, dim3(pnp::kRowsBlock), 0, s, uv, xyz, xyz_stride, ki, B, p, R, t, res,
-                           iters, rpy, pid);
+        const int64_t rows_blk = (B + pnp::kRowsBlock - 1) / pnp::kRowsBlock;
+        hipLaunchKernelGGL((pnp::qeif_rows6_kernel<T>), dim3(static_cast<unsigned>(rows_blk)), dim3(pnp::kRowsBlock), 0, s, uv, xyz,
+                           xyz_stride, ki, B, p, R, t, res, iters, rpy, pid);
         HIP_TRY(hipGetLastError());
+        note_launch(rows_blk, pnp::kRowsBlock, 0, "pnp::qeif_rows6_kernel<%s>", elem_name<T>());
         return PNP_OK;
     }
+    int rc = PNP_OK;
 #define PNP_Q(LPI_, NCT_)                                                                                    \
     do {                                                                                                     \
-        if (n_patterns > 1)                                                                                  \
-            hipLaunchKernelGGL((pnp::qeif_kernel<LPI_, NCT_, T, true>), grid, dim3(block), lds, s, uv, xyz,  \
-                               xyz_stride, n_patterns, ki, B, N, p, R, t, res, iters, rpy, pid);             \
-        else                                                                                                 \
-            hipLaunchKernelGGL((pnp::qeif_kernel<LPI_, NCT_, T, false>), grid, dim3(block), lds, s, uv, xyz, \
-                               xyz_stride, n_patterns, ki, B, N, p, R, t, res, iters, rpy, pid);             \
+        if (n_patterns > 1) {                                                                                \
+            auto kfn = pnp::qeif_kernel<LPI_, NCT_, T, true>;                                                \
+            if ((rc = allow_lds(reinterpret_cast<const void *>(kfn), lds)) != PNP_OK) break;                 \
+            hipLaunchKernelGGL(kfn, grid, dim3(block), lds, s, uv, xyz, xyz_stride, n_patterns, ki, B, N, p, \
+                               R, t, res, iters, rpy, pid);                                                  \
+        } else {                                                                                             \
+            auto kfn = pnp::qeif_kernel<LPI_, NCT_, T, false>;                                               \
+            if ((rc = allow_lds(reinterpret_cast<const void *>(kfn), lds)) != PNP_OK) break;                 \
+            hipLaunchKernelGGL(kfn, grid, dim3(block), lds, s, uv, xyz, xyz_stride, n_patterns, ki, B, N, p, \
+                               R, t, res, iters, rpy, pid);                                                  \
+        }                                                                                                    \
+        note_launch(nblk, block, lds, "pnp::qeif_kernel<%d, %d, %s, %s>", LPI_, NCT_, elem_name<T>(),        \
+                    n_patterns > 1 ? "true" : "false");                                                      \
     } while (0)
     switch (lpi) {
     case 1:
@@ -407,6 +562,7 @@ int launch_qeif(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, in
     default: PNP_Q(64, 0); break;
     }
 #undef PNP_Q
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return PNP_OK;
 }
@@ -420,22 +576,28 @@ int launch_dlt(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, con
     if (plan_B < B) plan_B = B;   // see launch_qeif
     const int lpi = choose_lpi(plan_B, N, xyz_stride != 0, 1, sizeof(T));
     const size_t lds = lds_bytes(lpi, N, xyz_stride != 0, 1, sizeof(T));
-    if (lds > 64 * 1024) return fail(PNP_E_ARG, "N = %d needs %zu bytes of LDS per workgroup (max 65536)", N, lds);
+    if (lds > kLdsMax) return fail(PNP_E_ARG, "N = %d needs %zu bytes of LDS per workgroup (max %zu)", N, lds, kLdsMax);
     constexpr int block = pnp::kSolveBlock<T>;
     const int64_t pb = block / lpi;
     const int64_t nblk = (B + pb - 1) / pb;
     if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
     const dim3 grid(static_cast<unsigned>(nblk));
     if (own_rows_ok(uv, xyz, xyz_stride, lpi, N, B, rows_on_device)) {
-        const dim3 rows_grid(static_cast<unsigned>((B + pnp::kRowsBlock - 1) / pnp::kRowsBlock));
-        hipLaunchKernelGGL((pnp::dlt_rows6_kernel<T>), rows_grid, dim3(pnp::kRowsBlock), 0, s, uv, xyz, xyz_stride, ki, B, N, num_it, R,
-                           t, res, rpy);
+        const int64_t rows_blk = (B + pnp::kRowsBlock - 1) / pnp::kRowsBlock;
+        hipLaunchKernelGGL((pnp::dlt_rows6_kernel<T>), dim3(static_cast<unsigned>(rows_blk)), dim3(pnp::kRowsBlock), 0, s, uv, xyz,
+                           xyz_stride, ki, B, N, num_it, R, t, res, rpy);
         HIP_TRY(hipGetLastError());
+        note_launch(rows_blk, pnp::kRowsBlock, 0, "pnp::dlt_rows6_kernel<%s>", elem_name<T>());
         return PNP_OK;
     }
-#define PNP_D(LPI_, NCT_)                                                                                \
-    hipLaunchKernelGGL((pnp::dlt_kernel<LPI_, NCT_, T>), grid, dim3(block), lds, s, uv, xyz, xyz_stride, \
-                       ki, B, N, num_it, R, t, res, rpy)
+    int rc = PNP_OK;
+#define PNP_D(LPI_, NCT_)                                                                                          \
+    do {                                                                                                           \
+        auto kfn = pnp::dlt_kernel<LPI_, NCT_, T>;                                                                 \
+        if ((rc = allow_lds(reinterpret_cast<const void *>(kfn), lds)) != PNP_OK) break;                           \
+        hipLaunchKernelGGL(kfn, grid, dim3(block), lds, s, uv, xyz, xyz_stride, ki, B, N, num_it, R, t, res, rpy); \
+        note_launch(nblk, block, lds, "pnp::dlt_kernel<%d, %d, %s>", LPI_, NCT_, elem_name<T>());                  \
+    } while (0)
     switch (lpi) {
     case 1:
         if (N == 6) PNP_D(1, 6); else PNP_D(1, 0);
@@ -448,6 +610,7 @@ int launch_dlt(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, con
     default: PNP_D(64, 0); break;
     }
 #undef PNP_D
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return PNP_OK;
 }
@@ -463,16 +626,19 @@ int launch_lm12(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_stride, co
         const size_t pb = pnp::kLmBlock / l;
         return (pb * 2 * N + (xyz_stride ? pb * 3 * N : static_cast<size_t>(3) * N)) * sizeof(T);
     };
-    while (lpi < 64 && lds_for(lpi) > static_cast<size_t>(kLdsBudget)) lpi *= 2;
+    while (lpi < 64 && lds_for(lpi) > kLdsAuto) lpi *= 2;
     const size_t lds = lds_for(lpi);
-    if (lds > 64 * 1024)
-        return fail(PNP_E_ARG, "N = %d needs %zu bytes of LDS per workgroup in the LM solver (max 65536)", N, lds);
+    if (lds > kLdsPlain)
+        return fail(PNP_E_ARG, "N = %d needs %zu bytes of LDS per workgroup in the LM solver (max %zu)", N, lds, kLdsPlain);
     const int64_t pb = pnp::kLmBlock / lpi;
     const int64_t nblk = (B + pb - 1) / pb;
     if (nblk > 0x7fffffffLL) return fail(PNP_E_ARG, "B = %lld needs too many workgroups", static_cast<long long>(B));
-#define PNP_L(LPI_)                                                                                              \
-    hipLaunchKernelGGL((pnp::lm12_kernel<T, LPI_>), dim3(static_cast<unsigned>(nblk)), dim3(pnp::kLmBlock), lds, s, \
-                       uv, xyz, xyz_stride, ki, B, N, lambda, num_it, R, t, res, rpy)
+#define PNP_L(LPI_)                                                                                                 \
+    do {                                                                                                            \
+        hipLaunchKernelGGL((pnp::lm12_kernel<T, LPI_>), dim3(static_cast<unsigned>(nblk)), dim3(pnp::kLmBlock), lds, s, \
+                           uv, xyz, xyz_stride, ki, B, N, lambda, num_it, R, t, res, rpy);                          \
+        note_launch(nblk, pnp::kLmBlock, lds, "pnp::lm12_kernel<%s, %d>", elem_name<T>(), LPI_);                    \
+    } while (0)
     switch (lpi) {
     case 1: PNP_L(1); break;
     case 2: PNP_L(2); break;
@@ -497,16 +663,25 @@ struct SolveIO {
     int32_t *iters, *pid;
 };
 
-// Grow-only resources of one pipeline lane of the current device; caller holds the staging lock.
-int lane_reserve(PipeLane &ln, size_t pinned_bytes)
+// Grow-only resources of one pipeline lane of the current device; called by the lane's own thread.
+int lane_reserve(PipeLane &ln, size_t pinned_bytes, size_t pattern_bytes)
 {
     if (!ln.stream) HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
     if (pinned_bytes > ln.pinned_cap) {
         if (ln.pinned) HIP_TRY(hipHostFree(ln.pinned));
-        ln.pinned = nullptr;
+        ln.pinned = ln.pinned_dev = nullptr;
         ln.pinned_cap = 0;
         HIP_TRY(hipHostMalloc(&ln.pinned, pinned_bytes, hipHostMallocDefault));
         ln.pinned_cap = pinned_bytes;
+        HIP_TRY(hipHostGetDevicePointer(&ln.pinned_dev, ln.pinned, 0));
+    }
+    if (pattern_bytes > ln.pattern_cap) {
+        if (ln.pattern) HIP_TRY(hipFree(ln.pattern));
+        ln.pattern = nullptr;
+        ln.pattern_cap = 0;
+        ln.pattern_of = 0;
+        HIP_TRY(hipMalloc(&ln.pattern, pattern_bytes + 256));
+        ln.pattern_cap = pattern_bytes + 256;
     }
     return PNP_OK;
 }
@@ -592,14 +767,17 @@ bool map_page_locked(const SolveIO<T> &h, SolveIO<T> &d)
     return true;
 }
 
-// The chunked form of a host-pointer call (see kPipeLanes).  per_in / per_out: array elements per
-// problem that go in (uv, and xyz when every problem has its own) and come out.  The shared
-// pattern, if any, is already on the device at d_shared_xyz.  run(d, first, count, stream) solves
-// problems [first, first + count) from device pointers d that point at the chunk's own arrays.
+// The chunked form of a host-pointer call (see kPipeLanes).  xyz_elems: elements of the shared
+// pattern(s) when own_xyz is false.  run(d, count, stream) solves `count` problems from device
+// pointers d that point at the chunk's own arrays; it is called on the lane threads, with the
+// caller's tuning overrides in force.
 template <typename T, typename Run>
-int pipelined_host_call(Staging &st, int dev, hipStream_t s, int64_t B, int32_t N, bool own_xyz,
-                        const T *d_shared_xyz, const SolveIO<T> &h, Run run)
+int pipelined_host_call(int dev, hipStream_t s, int64_t B, int32_t N, bool own_xyz, size_t xyz_elems,
+                        const SolveIO<T> &h, Run run)
 {
+    LanePool &pool = g_lanes[dev];
+    int rc = pool.ensure_started(dev);
+    if (rc) return rc;
     // chunks of about kPipeChunkBytes of input; smaller ones (down to an eighth) for calls that
     // would not give every lane two chunks otherwise
     const size_t in_per = (2 * static_cast<size_t>(N) + (own_xyz ? 3 * static_cast<size_t>(N) : 0)) * sizeof(T);
@@ -608,10 +786,9 @@ int pipelined_host_call(Staging &st, int dev, hipStream_t s, int64_t B, int32_t 
     int64_t chunk = static_cast<int64_t>(chunk_bytes / in_per);
     chunk = std::max<int64_t>(1024, chunk & ~int64_t(255));
     const int64_t nchunks = (B + chunk - 1) / chunk;
-    const int lanes = static_cast<int>(std::min<int64_t>(kPipeLanes, nchunks));
     // layout of a lane's page-locked buffer
     struct Layout {
-        size_t uv, xyz, R, t, res, rpy, iters, pid, in_end, end;
+        size_t uv, xyz, R, t, res, rpy, iters, pid, end;
     } lay;
     {
         size_t off = 0;
@@ -623,7 +800,6 @@ int pipelined_host_call(Staging &st, int dev, hipStream_t s, int64_t B, int32_t 
         const size_t n = static_cast<size_t>(chunk);
         lay.uv = take(n * 2 * N * sizeof(T));
         lay.xyz = own_xyz ? take(n * 3 * N * sizeof(T)) : off;
-        lay.in_end = off;
         lay.R = take(n * 9 * sizeof(T));
         lay.t = take(n * 3 * sizeof(T));
         lay.res = h.res ? take(n * sizeof(T)) : off;
@@ -632,14 +808,8 @@ int pipelined_host_call(Staging &st, int dev, hipStream_t s, int64_t B, int32_t 
         lay.pid = h.pid ? take(n * sizeof(int32_t)) : off;
         lay.end = off;
     }
-    for (int l = 0; l < lanes; ++l) {
-        const int rc = lane_reserve(st.lane[l], lay.end);
-        if (rc) return rc;
-    }
-    // the lanes' streams start after whatever the caller's stream holds at this point
-    if (!st.entry) HIP_TRY(hipEventCreateWithFlags(&st.entry, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(st.entry, s));
-    for (int l = 0; l < lanes; ++l) HIP_TRY(hipStreamWaitEvent(st.lane[l].stream, st.entry, 0));
+    // the lanes' streams know nothing of the caller's: what it holds is waited for here
+    HIP_TRY(hipStreamSynchronize(s));
 
     // a side of the call whose arrays are all page-locked is given to the kernels as it is
     SolveIO<T> m{};   // device addresses of the caller's page-locked arrays
@@ -668,83 +838,117 @@ int pipelined_host_call(Staging &st, int dev, hipStream_t s, int64_t B, int32_t 
     m.iters = static_cast<int32_t *>(q_iters);
     m.pid = static_cast<int32_t *>(q_pid);
 
-    struct Outcome {
+    // what the lanes report back to this call
+    struct Progress {
+        std::mutex mu;
+        std::condition_variable done;
+        int64_t left;
         int rc = PNP_OK;
         char msg[sizeof g_err] = "";
-    };
-    Outcome outcome[kPipeLanes];
-    auto work = [&](int l) {
-        Outcome &oc = outcome[l];
-        PipeLane &ln = st.lane[l];
-        auto body = [&]() -> int {
-            HIP_TRY(hipSetDevice(dev));
-            char *pin = static_cast<char *>(ln.pinned);
-            void *mapped = nullptr;
-            HIP_TRY(hipHostGetDevicePointer(&mapped, pin, 0));
-            char *mp = static_cast<char *>(mapped);   // the lane's buffer as the device sees it
-            for (int64_t k = l; k < nchunks; k += lanes) {
-                const int64_t first = k * chunk;
-                const size_t n = static_cast<size_t>(std::min<int64_t>(chunk, B - first));
-                SolveIO<T> d;
-                if (in_locked) {
-                    d.uv = m.uv + first * 2 * N;
-                    d.xyz = own_xyz ? m.xyz + first * 3 * N : d_shared_xyz;
-                } else {
-                    copy_streaming(pin + lay.uv, h.uv + first * 2 * N, n * 2 * N * sizeof(T));
-                    if (own_xyz) copy_streaming(pin + lay.xyz, h.xyz + first * 3 * N, n * 3 * N * sizeof(T));
-                    d.uv = reinterpret_cast<const T *>(mp + lay.uv);
-                    d.xyz = own_xyz ? reinterpret_cast<const T *>(mp + lay.xyz) : d_shared_xyz;
-                }
-                if (out_locked) {
-                    d.R = m.R + first * 9;
-                    d.t = m.t + first * 3;
-                    d.res = h.res ? m.res + first : nullptr;
-                    d.rpy = h.rpy ? m.rpy + first * 3 : nullptr;
-                    d.iters = h.iters ? m.iters + first : nullptr;
-                    d.pid = h.pid ? m.pid + first : nullptr;
-                } else {
-                    d.R = reinterpret_cast<T *>(mp + lay.R);
-                    d.t = reinterpret_cast<T *>(mp + lay.t);
-                    d.res = h.res ? reinterpret_cast<T *>(mp + lay.res) : nullptr;
-                    d.rpy = h.rpy ? reinterpret_cast<T *>(mp + lay.rpy) : nullptr;
-                    d.iters = h.iters ? reinterpret_cast<int32_t *>(mp + lay.iters) : nullptr;
-                    d.pid = h.pid ? reinterpret_cast<int32_t *>(mp + lay.pid) : nullptr;
-                }
-                const int rc = run(d, static_cast<int64_t>(n), ln.stream);
-                if (rc) return rc;
-                // the lane's buffer is reused by its next chunk, and read below
-                HIP_TRY(hipStreamSynchronize(ln.stream));
-                if (out_locked) continue;
-                copy_streaming(h.R + first * 9, pin + lay.R, n * 9 * sizeof(T));
-                copy_streaming(h.t + first * 3, pin + lay.t, n * 3 * sizeof(T));
-                if (h.res) copy_streaming(h.res + first, pin + lay.res, n * sizeof(T));
-                if (h.rpy) copy_streaming(h.rpy + first * 3, pin + lay.rpy, n * 3 * sizeof(T));
-                if (h.iters) copy_streaming(h.iters + first, pin + lay.iters, n * sizeof(int32_t));
-                if (h.pid) copy_streaming(h.pid + first, pin + lay.pid, n * sizeof(int32_t));
+        LaunchRecord launch;
+    } progress;
+    progress.left = nchunks;
+    const uint64_t serial = ++g_call_serial;
+    const Tuning tuning = g_tuning;
+    const size_t pattern_bytes = own_xyz ? 0 : xyz_elems * sizeof(T);
+
+    auto carry = [&](PipeLane &ln, int64_t k) -> int {
+        g_tuning = tuning;
+        int rc2 = lane_reserve(ln, lay.end, pattern_bytes);
+        if (rc2) return rc2;
+        const T *d_shared = nullptr;
+        if (!own_xyz) {   // the shared pattern(s) go up once per lane and call
+            if (ln.pattern_of != serial) {
+                HIP_TRY(hipMemcpyAsync(ln.pattern, h.xyz, pattern_bytes, hipMemcpyHostToDevice, ln.stream));
+                ln.pattern_of = serial;
             }
-            return PNP_OK;
-        };
-        oc.rc = body();
-        if (oc.rc) std::memcpy(oc.msg, g_err, sizeof oc.msg);   // g_err is this thread's own
-        (void)hipStreamSynchronize(ln.stream);                  // nothing of this lane stays in flight
-    };
-    // lanes 1.. on helper threads; a lane whose thread cannot be started is worked off here,
-    // after lane 0 (nothing may be thrown through the C ABI)
-    std::vector<std::thread> helpers;
-    int started = 1;
-    try {
-        helpers.reserve(lanes - 1);
-        for (; started < lanes; ++started) helpers.emplace_back(work, started);
-    } catch (...) {
-    }
-    work(0);
-    for (int l = started; l < lanes; ++l) work(l);
-    for (auto &th : helpers) th.join();
-    for (int l = 0; l < lanes; ++l)
-        if (outcome[l].rc) {
-            std::memcpy(g_err, outcome[l].msg, sizeof g_err);
-            return outcome[l].rc;
+            d_shared = static_cast<const T *>(ln.pattern);
         }
+        char *pin = static_cast<char *>(ln.pinned);
+        char *mp = static_cast<char *>(ln.pinned_dev);   // the lane's buffer as the device sees it
+        const int64_t first = k * chunk;
+        const size_t n = static_cast<size_t>(std::min<int64_t>(chunk, B - first));
+        SolveIO<T> d;
+        if (in_locked) {
+            d.uv = m.uv + first * 2 * N;
+            d.xyz = own_xyz ? m.xyz + first * 3 * N : d_shared;
+        } else {
+            copy_streaming(pin + lay.uv, h.uv + first * 2 * N, n * 2 * N * sizeof(T));
+            if (own_xyz) copy_streaming(pin + lay.xyz, h.xyz + first * 3 * N, n * 3 * N * sizeof(T));
+            d.uv = reinterpret_cast<const T *>(mp + lay.uv);
+            d.xyz = own_xyz ? reinterpret_cast<const T *>(mp + lay.xyz) : d_shared;
+        }
+        if (out_locked) {
+            d.R = m.R + first * 9;
+            d.t = m.t + first * 3;
+            d.res = h.res ? m.res + first : nullptr;
+            d.rpy = h.rpy ? m.rpy + first * 3 : nullptr;
+            d.iters = h.iters ? m.iters + first : nullptr;
+            d.pid = h.pid ? m.pid + first : nullptr;
+        } else {
+            d.R = reinterpret_cast<T *>(mp + lay.R);
+            d.t = reinterpret_cast<T *>(mp + lay.t);
+            d.res = h.res ? reinterpret_cast<T *>(mp + lay.res) : nullptr;
+            d.rpy = h.rpy ? reinterpret_cast<T *>(mp + lay.rpy) : nullptr;
+            d.iters = h.iters ? reinterpret_cast<int32_t *>(mp + lay.iters) : nullptr;
+            d.pid = h.pid ? reinterpret_cast<int32_t *>(mp + lay.pid) : nullptr;
+        }
+        rc2 = run(d, static_cast<int64_t>(n), ln.stream);
+        if (rc2) return rc2;
+        // the lane's buffer is read below, and reused by the lane's next chunk
+        HIP_TRY(hipStreamSynchronize(ln.stream));
+        if (out_locked) return PNP_OK;
+        copy_streaming(h.R + first * 9, pin + lay.R, n * 9 * sizeof(T));
+        copy_streaming(h.t + first * 3, pin + lay.t, n * 3 * sizeof(T));
+        if (h.res) copy_streaming(h.res + first, pin + lay.res, n * sizeof(T));
+        if (h.rpy) copy_streaming(h.rpy + first * 3, pin + lay.rpy, n * 3 * sizeof(T));
+        if (h.iters) copy_streaming(h.iters + first, pin + lay.iters, n * sizeof(int32_t));
+        if (h.pid) copy_streaming(h.pid + first, pin + lay.pid, n * sizeof(int32_t));
+        return PNP_OK;
+    };
+    auto job = [&](PipeLane &ln, int64_t k) {
+        bool skip;
+        {
+            std::lock_guard<std::mutex> lock(progress.mu);
+            skip = progress.rc != PNP_OK;   // an earlier chunk failed: the call is lost already
+        }
+        int rc2 = PNP_OK;
+        if (!skip) {
+            rc2 = carry(ln, k);
+            if (rc2 && ln.stream) (void)hipStreamSynchronize(ln.stream);   // nothing of this chunk stays in flight
+        }
+        std::lock_guard<std::mutex> lock(progress.mu);
+        if (rc2 && progress.rc == PNP_OK) {
+            progress.rc = rc2;
+            std::memcpy(progress.msg, g_err, sizeof progress.msg);   // g_err is the lane thread's own
+        }
+        if (!skip && !rc2) progress.launch = g_last_launch;
+        if (--progress.left == 0) progress.done.notify_all();
+    };
+    {
+        std::lock_guard<std::mutex> lock(pool.mu);
+        int64_t queued = 0;
+        try {
+            for (int64_t k = 0; k < nchunks; ++k, ++queued)
+                pool.chunks.emplace_back([&job, k](PipeLane &ln) { job(ln, k); });
+        } catch (...) {
+            // the chunks queued so far refer to this frame: they are waited for below like any others
+            std::lock_guard<std::mutex> plock(progress.mu);
+            progress.left -= nchunks - queued;
+            progress.rc = PNP_E_HIP;
+            snprintf(progress.msg, sizeof progress.msg, "out of memory while queueing the chunks of a host-pointer call");
+        }
+    }
+    pool.wake.notify_all();
+    {
+        std::unique_lock<std::mutex> lock(progress.mu);
+        progress.done.wait(lock, [&] { return progress.left <= 0; });
+    }
+    if (progress.rc) {
+        std::memcpy(g_err, progress.msg, sizeof g_err);
+        return progress.rc;
+    }
+    g_last_launch = progress.launch;
     return PNP_OK;
 }
 
@@ -770,19 +974,10 @@ int with_host_staging(hipStream_t s, int64_t B, int32_t N, size_t xyz_elems, boo
             return run(d, B, s);
         }
     }
+    if ((nB * 2 * N + (own_xyz ? xyz_elems : 0) + nB * 12) * sizeof(T) >= kPipeMinBytes)
+        return pipelined_host_call<T>(dev, s, B, N, own_xyz, xyz_elems, h, run);
     Staging &st = g_staging[dev];
     std::lock_guard<std::mutex> lock(st.mu);
-    if ((nB * 2 * N + (own_xyz ? xyz_elems : 0) + nB * 12) * sizeof(T) >= kPipeMinBytes) {
-        const T *d_shared = nullptr;
-        if (!own_xyz) {   // the shared pattern(s) go up once, ahead of the lanes
-            int rc = staging_reserve(st, xyz_elems * sizeof(T) + 256);
-            if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(st.buf, h.xyz, xyz_elems * sizeof(T), hipMemcpyHostToDevice, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            d_shared = static_cast<const T *>(st.buf);
-        }
-        return pipelined_host_call<T>(st, dev, s, B, N, own_xyz, d_shared, h, run);
-    }
     // Smaller calls: one page-locked buffer holds inputs and results, the kernels work on it over
     // the bus (no device staging, no copy operations), the caller's stream carries the launch.
     const size_t total = 256 * 10 + (nB * 2 * N + xyz_elems + nB * (9 + 3 + 1 + 3)) * sizeof(T) +
@@ -1339,7 +1534,7 @@ int pnp_set_lanes_per_problem(int32_t lanes)
     g_err[0] = 0;
     if (lanes != 0 && (lanes < 1 || lanes > 64 || (lanes & (lanes - 1)) != 0))
         return fail(PNP_E_ARG, "lanes = %d is not 0 or a power of two in [1, 64]", lanes);
-    g_forced_lpi.store(lanes);
+    g_tuning.forced_lpi = lanes;
     return PNP_OK;
 }
 
@@ -1348,13 +1543,29 @@ int pnp_set_qeif_form(int32_t form)
     g_err[0] = 0;
     if (form != PNP_QEIF_FORM_AUTO && form != PNP_QEIF_FORM_POINTS && form != PNP_QEIF_FORM_MOMENTS)
         return fail(PNP_E_ARG, "form = %d is not one of PNP_QEIF_FORM_*", form);
-    g_qeif_form.store(form);
+    g_tuning.qeif_form = form;
     return PNP_OK;
 }
 
 int pnp_get_qeif_form(int64_t B, int32_t N)
 {
     return use_moment_form(B, N, 1) ? PNP_QEIF_FORM_MOMENTS : PNP_QEIF_FORM_POINTS;
+}
+
+const char *pnp_last_kernel_name(void) { return g_last_launch.kernel; }
+
+void pnp_last_launch(int64_t *grid, int32_t *block, int32_t *lds_bytes_out)
+{
+    if (grid) *grid = g_last_launch.grid;
+    if (block) *block = g_last_launch.block;
+    if (lds_bytes_out) *lds_bytes_out = g_last_launch.lds;
+}
+
+int pnp_host_lane_threads(int device)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(PNP_E_ARG, "device %d outside [0, %d)", device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_lanes[device].mu);
+    return static_cast<int>(g_lanes[device].threads.size());
 }
 
 int pnp_get_lanes_per_problem(int64_t B, int32_t N, int64_t xyz_problem_stride)
@@ -1367,6 +1578,13 @@ int pnp_max_points(void) { return kMaxPoints; }
 
 const char *pnp_last_error(void) { return g_err; }
 
-const char *pnp_version(void) { return "pnp_hip 0.4 (gfx950)"; }
+const char *pnp_version(void)
+{
+#ifdef PNP_AB_SWITCHES
+    return "pnp_hip 0.5 (gfx950; A/B build: reads PNP_ROWS_STAGED and PNP_MOMENT_PLAIN)";
+#else
+    return "pnp_hip 0.5 (gfx950)";
+#endif
+}
 
 }  // extern "C"

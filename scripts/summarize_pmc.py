@@ -13,7 +13,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", "pmc")
 
 # dispatch order of scripts/pmc_probe.py: 3 launches each
@@ -22,6 +22,9 @@ LAUNCHES = [("qeif_n6_b1m_per_problem_xyz", "qeif_rows6_kernel<", 1 << 20, 6, Tr
             ("qeif_n6_b1m_shared_pattern", "qeif_rows6_kernel<", 1 << 20, 6, False),
             ("qeif_n68_b256k_shared_pattern", "qeif_moment_kernel<float, 16, true>", 1 << 18, 68, False),
             ("qeif_n68_b256k_per_problem_xyz", "qeif_moment_lines_kernel<float>", 1 << 18, 68, True)]
+
+
+KERNEL_SEEN = {}   # label -> kernel name the counter rows carry (without "void" and the argument list)
 
 
 def load(name):
@@ -47,6 +50,7 @@ def per_launch(name):
             continue
         keys = [k for k in chunk[0] if k != "kernel"]
         out[label] = {k: sum(d[k] for d in chunk) / len(chunk) for k in keys}
+        KERNEL_SEEN[label] = chunk[0]["kernel"].split("(")[0].replace("void ", "").strip()
     return out
 
 
@@ -112,11 +116,24 @@ for label, kern, B, N, own in LAUNCHES:
         s["valu_busy_frac"] = round(4 * s["SQ_ACTIVE_INST_VALU"] / 1024 / (s["GRBM_GUI_ACTIVE"] / 8), 4)
         s["valu_insts_per_wave"] = round(s["SQ_INSTS_VALU"] / s["SQ_WAVES"], 1)
     traffic[label + "_bytes_per_launch"] = round(s["hbm_bytes_per_launch"])
+    if "valu_insts_per_wave" in s:
+        traffic[label + "_valu_insts_per_wave"] = s["valu_insts_per_wave"]
 
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 json.dump(summary, open(os.path.join(ROOT, "profiles", tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
 traffic["qeif_n6_b1m_bytes_per_launch"] = traffic.get("qeif_n6_b1m_per_problem_xyz_bytes_per_launch")
-traffic["source"] = "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % tag
+traffic["source"] = "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_*, separate passes)" % tag
+traffic["kernels"] = dict(KERNEL_SEEN)
+import subprocess
+try:
+    traffic["commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                                       timeout=30).stdout.strip() or None
+    dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "pnp_solver_test_amd", "include"],
+                           capture_output=True, text=True, timeout=30).stdout.strip()
+    if dirty:
+        traffic["commit"] += " + uncommitted changes to the library sources"
+except Exception:
+    traffic["commit"] = None
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1, sort_keys=True)
 for label, s in summary.items():
     print(label, {k: s[k] for k in ("hbm_bytes_per_launch", "fetch_2x_over_input", "read_bytes_over_input", "valu_busy_frac", "valu_insts_per_wave") if k in s})

@@ -23,6 +23,10 @@ from pnp_solver_test_amd import _lib
 
 pytestmark = pytest.mark.gpu
 
+#: the library built with -DPNP_AB_SWITCHES (reads PNP_ROWS_STAGED / PNP_MOMENT_PLAIN); second
+#: processes of the variant-equality tests load it through PNP_HIP_LIB
+AB_LIB = _lib.LIB_PATH.replace("libpnp_hip.so", "libpnp_hip_ab.so")
+
 K = po.K_DEFAULT
 P6 = po.pattern_array(po.PATTERN_ALEXANDER, po.LM6_KEYS)
 P6f = P6.astype(np.float32)
@@ -1402,8 +1406,8 @@ def test_moment_form_line_cut_staging(torch_dev, moment_form, N, f64):
 
 def test_line_cut_staging_equals_equal_chunk_staging(torch_dev, tmp_path):
     """The two staging schemes of the moment form (per-problem patterns) form their sums in the
-    same order: a second process that keeps the equal-chunk kernel (PNP_MOMENT_PLAIN=1 is read when
-    the library is loaded) must return the same bits."""
+    same order: a second process that loads the A/B build of the library and keeps the equal-chunk
+    kernel (PNP_MOMENT_PLAIN=1, read by that build only) must return the same bits."""
     import os
     import subprocess
     import sys
@@ -1421,28 +1425,34 @@ def test_line_cut_staging_equals_equal_chunk_staging(torch_dev, tmp_path):
         "import pnp_solver_test_amd as pnp\n"
         "from pnp_solver_test_amd import _lib, synth\n"
         "_lib.load().pnp_set_qeif_form(_lib.QEIF_FORM_MOMENTS)\n"
-        "d = np.load(%r); out = {}\n"
+        "d = np.load(%r); out = {}; kernels = []\n"
         "for n in (32, 68):\n"
         "    for tag, dt in (('f32', torch.float32), ('f64', torch.float64)):\n"
         "        o = pnp.solve_pnp_batch(torch.from_numpy(d['uv%%d' %% n]).cuda().to(dt), torch.from_numpy(d['xyz%%d' %% n]).cuda().to(dt), synth.K_DEFAULT)\n"
         "        out['R%%d%%s' %% (n, tag)] = o['R'].cpu().numpy(); out['t%%d%%s' %% (n, tag)] = o['t'].cpu().numpy(); out['i%%d%%s' %% (n, tag)] = o['iters'].cpu().numpy()\n"
-        "np.savez(sys.argv[1], **out)\n"
+        "        kernels.append(_lib.last_launch()['kernel'])\n"
+        "np.savez(sys.argv[1], kernels=np.array(kernels), **out)\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "in.npz"))
     outs = {}
-    for tag, env in (("lines", {}), ("plain", {"PNP_MOMENT_PLAIN": "1"})):
+    for tag, env in (("lines", {}), ("plain", {"PNP_HIP_LIB": AB_LIB, "PNP_MOMENT_PLAIN": "1"})):
         path = str(tmp_path / (tag + ".npz"))
         r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=240)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[tag] = np.load(path)
-    assert sorted(outs["lines"].files) == sorted(outs["plain"].files) and len(outs["lines"].files) == 12
+    assert sorted(outs["lines"].files) == sorted(outs["plain"].files) and len(outs["lines"].files) == 13
+    # the two processes did run different kernels (names as the library reports them) ...
+    assert all(str(k).startswith("pnp::qeif_moment_lines_kernel<") for k in outs["lines"]["kernels"])
+    assert all(str(k).startswith("pnp::qeif_moment_kernel<") and str(k).endswith("false>") for k in outs["plain"]["kernels"])
+    # ... and a stray PNP_MOMENT_PLAIN does nothing to the library proper
     for k in outs["lines"].files:
-        assert np.array_equal(outs["lines"][k], outs["plain"][k]), k
+        if k != "kernels":
+            assert np.array_equal(outs["lines"][k], outs["plain"][k]), k
 
 
 def test_row_reading_kernels_equal_the_staged_kernels(golden, torch_dev, tmp_path):
     """Six-point launches on aligned rows in device memory are solved by lanes that read their own
-    rows; a second process that keeps the LDS-staged kernels (PNP_ROWS_STAGED=1 is read when the
-    library is loaded) must return the same bits: QEIF (with iteration counts, residuals and
+    rows; a second process that loads the A/B build of the library and keeps the LDS-staged kernels
+    (PNP_ROWS_STAGED=1, read by that build only; the library proper ignores it) must return the same bits: QEIF (with iteration counts, residuals and
     angles) and DLT through the C ABI, both element types, a pattern per problem, a shared one and
     pattern rows 26 elements apart, a batch that ends inside a wavefront, and planar patterns,
     which take the DLT kernels' pseudo-inverse path."""
@@ -1458,7 +1468,7 @@ def test_row_reading_kernels_equal_the_staged_kernels(golden, torch_dev, tmp_pat
         "sys.path.insert(0, %r)\n"
         "import pnp_solver_test_amd as pnp\n"
         "from pnp_solver_test_amd import _lib, synth\n"
-        "lib = _lib.load(); d = np.load(%r); out = {}; K = _lib.k_array(synth.K_DEFAULT)\n"
+        "lib = _lib.load(); d = np.load(%r); out = {}; kernels = []; K = _lib.k_array(synth.K_DEFAULT)\n"
         "st = torch.cuda.current_stream().cuda_stream\n"
         "def run(tag, m, uv, xyz, stride):\n"
         "    B, sfx, dt = uv.shape[0], ('f32' if uv.dtype == torch.float32 else 'f64'), uv.dtype\n"
@@ -1472,6 +1482,7 @@ def test_row_reading_kernels_equal_the_staged_kernels(golden, torch_dev, tmp_pat
         "    _lib.check(rc); torch.cuda.synchronize()\n"
         "    for k, v in (('R', R), ('t', t), ('res', res), ('rpy', rpy), ('iters', it)):\n"
         "        out['%%s_%%s_%%s_%%s' %% (sfx, tag, m, k)] = v.cpu().numpy()\n"
+        "    kernels.append(_lib.last_launch()['kernel'])\n"
         "uv32 = torch.from_numpy(d['uv']).cuda(); P32 = torch.from_numpy(d['P']).cuda(); B = uv32.shape[0]\n"
         "wide32 = torch.zeros((B, 26), device='cuda'); wide32[:, :18] = P32.reshape(18)\n"
         "for dt in (torch.float32, torch.float64):\n"
@@ -1480,17 +1491,21 @@ def test_row_reading_kernels_equal_the_staged_kernels(golden, torch_dev, tmp_pat
         "    for m in ('qeif', 'dlt'):\n"
         "        run('own', m, uv, own, 18); run('shared', m, uv, shared, 0); run('wide', m, uv, wide, 26)\n"
         "    run('planar', 'dlt', up, pp, 18)\n"
-        "np.savez(sys.argv[1], **out)\n"
+        "np.savez(sys.argv[1], kernels=np.array(kernels), **out)\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "in.npz"))
     outs = {}
-    for tag, env in (("rows", {}), ("staged", {"PNP_ROWS_STAGED": "1"})):
+    for tag, env in (("rows", {"PNP_ROWS_STAGED": "1"}), ("staged", {"PNP_HIP_LIB": AB_LIB, "PNP_ROWS_STAGED": "1"})):
         path = str(tmp_path / (tag + ".npz"))
         r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=240)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[tag] = np.load(path)
-    assert sorted(outs["rows"].files) == sorted(outs["staged"].files) and len(outs["rows"].files) == 2 * 7 * 5
+    assert sorted(outs["rows"].files) == sorted(outs["staged"].files) and len(outs["rows"].files) == 2 * 7 * 5 + 1
+    # the library proper ran the row-reading kernels although PNP_ROWS_STAGED was set; the A/B build the staged ones
+    assert all("_rows6_kernel<" in str(k) for k in outs["rows"]["kernels"])
+    assert all(str(k).startswith(("pnp::qeif_kernel<1, 6,", "pnp::dlt_kernel<1, 6,")) for k in outs["staged"]["kernels"])
     for k in outs["rows"].files:
-        assert np.array_equal(outs["rows"][k], outs["staged"][k], equal_nan=True), k
+        if k != "kernels":
+            assert np.array_equal(outs["rows"][k], outs["staged"][k], equal_nan=True), k
     # ... and the row-reading results are the solver's, not two equal failures
     ref = solve_dev(uv[:B], P6f, torch_dev)
     assert np.array_equal(outs["rows"]["f32_own_qeif_R"].reshape(B, 3, 3), ref["R"])

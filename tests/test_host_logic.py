@@ -92,6 +92,70 @@ def test_lanes_per_problem_heuristic():
     assert lib.pnp_get_lanes_per_problem(1, 6, 0) >= 2
 
 
+def test_loading_the_library_starts_no_thread_and_reads_no_environment():
+    """The host-pointer pipeline's threads belong to the first call that is large enough to be
+    chunked: loading the library alone starts none.  And the library proper carries no getenv: the
+    A/B switches live in a second build."""
+    import subprocess
+    import sys
+    code = ("import os, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "os.environ['PNP_HIP_NO_TORCH'] = '1'\n"
+            "from pnp_solver_test_amd import _lib\n"
+            "before = len(os.listdir('/proc/self/task'))\n"
+            "lib = _lib.load()\n"
+            "lib.pnp_version(); lib.pnp_get_lanes_per_problem(1 << 20, 6, 18); lib.pnp_last_kernel_name()\n"
+            "print(before, len(os.listdir('/proc/self/task')), lib.pnp_host_lane_threads(0))\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    before, after, lanes = (int(v) for v in r.stdout.split())
+    assert after == before and lanes == 0
+    lib = _lib.load()
+    assert lib.pnp_host_lane_threads(0) == 0 and lib.pnp_host_lane_threads(-1) == -1
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in undefined and "hipLaunchKernel" in undefined
+    ab = _lib.LIB_PATH.replace("libpnp_hip.so", "libpnp_hip_ab.so")
+    if os.path.exists(ab):
+        assert "getenv" in subprocess.run(["nm", "-D", "--undefined-only", ab], capture_output=True, text=True).stdout
+        assert b"A/B" not in lib.pnp_version()
+
+
+def test_tuning_overrides_belong_to_the_calling_thread():
+    """pnp_set_lanes_per_problem / pnp_set_qeif_form change the launches of the thread that called
+    them and of no other."""
+    import threading
+    lib = _lib.load()
+    seen = {}
+
+    def other():
+        seen["lanes"] = lib.pnp_get_lanes_per_problem(1 << 20, 6, 18)
+        seen["form"] = lib.pnp_get_qeif_form(1 << 18, 68)
+        lib.pnp_set_lanes_per_problem(8)          # ... and must not leak back either
+        seen["own"] = lib.pnp_get_lanes_per_problem(1 << 20, 6, 18)
+
+    lib.pnp_set_lanes_per_problem(16)
+    lib.pnp_set_qeif_form(_lib.QEIF_FORM_POINTS)
+    try:
+        assert lib.pnp_get_lanes_per_problem(1 << 20, 6, 18) == 16
+        th = threading.Thread(target=other)
+        th.start()
+        th.join()
+        assert seen == dict(lanes=1, form=_lib.QEIF_FORM_MOMENTS, own=8)
+        assert lib.pnp_get_lanes_per_problem(1 << 20, 6, 18) == 16
+        assert lib.pnp_get_qeif_form(1 << 18, 68) == _lib.QEIF_FORM_POINTS
+    finally:
+        lib.pnp_set_lanes_per_problem(0)
+        lib.pnp_set_qeif_form(_lib.QEIF_FORM_AUTO)
+    # a forced lane count may take all of a compute unit's LDS: one lane per problem fits 68 points
+    lib.pnp_set_lanes_per_problem(1)
+    try:
+        assert lib.pnp_get_lanes_per_problem(1 << 18, 68, 0) == 1
+        assert lib.pnp_get_lanes_per_problem(1 << 18, 512, 3 * 512) >= 8
+    finally:
+        lib.pnp_set_lanes_per_problem(0)
+    assert _lib.last_launch()["kernel"] == "" or _lib.last_launch()["kernel"].startswith("pnp::")
+
+
 def test_python_argument_checks():
     with pytest.raises(ValueError):
         pnp.solve_pnp_batch(np.zeros((4, 6, 3), np.float32), np.zeros((6, 3), np.float32), K)

@@ -1,6 +1,9 @@
 """pnp_qeif_batch_noalloc_f32: the host-pointer QEIF call that stages through a static device
-array instead of hipMalloc'ed buffers.  Same kernels as pnp_qeif_batch_f32, so every output must
-be bit-identical to that entry point's on the same host arrays; the oracle bounds both."""
+array instead of buffers the library allocates.  Every output must be bit-identical to
+pnp_qeif_batch_f32's on the same host arrays; the oracle bounds both.  The two need not run the same
+kernel: the static array is device memory, so large six-point batches are solved there by lanes
+that read their own rows, while the host-pointer path launches the LDS-staged kernel on host
+memory - the last test holds the two to the same bits through both entry points."""
 import ctypes
 
 import numpy as np
@@ -68,7 +71,7 @@ def test_noalloc_entry_point_equals_the_allocating_one(golden):
                                            None) == 0
 
 
-def test_noalloc_entry_point_rejects_what_does_not_fit():
+def test_noalloc_entry_point_rejects_what_does_not_fit(golden):
     lib = _lib.load()
     per_problem = (2 * 6 + 3 * 6 + 9 + 3 + 1 + 3) * 4 + 4
     B = _lib.NOALLOC_SCRATCH_BYTES // per_problem + 1          # one more than could ever fit
@@ -83,9 +86,21 @@ def test_noalloc_entry_point_rejects_what_does_not_fit():
     # the largest batch the message names does fit
     fits = int(msg.split("at most ")[1].split(" problems")[0])
     assert 0 < fits < B
-    uv2 = np.ascontiguousarray(np.broadcast_to(np.array([[170., 130.], [150., 130.], [168., 150.], [152., 150.],
-                                                         [158., 143.], [160., 165.]], np.float32), (fits, 6, 2)))
-    o2 = _outputs(fits)
-    assert _call(lib.pnp_qeif_batch_noalloc_f32, uv2, np.ascontiguousarray(own[:fits] + P6f), 18, o2, None) == 0, \
-        lib.pnp_last_error()
-    assert np.isfinite(o2["R"]).all() and (o2["R"] == o2["R"][0]).all()
+    g = golden("stress_qeif_n6")
+    uv6 = np.ascontiguousarray(g["uv15"][:, lm6_indices(g), :], dtype=np.float32)
+    uv2 = np.ascontiguousarray(np.tile(uv6, (fits // len(uv6) + 1, 1, 1))[:fits])
+    own2 = np.ascontiguousarray(own[:fits] + P6f)
+    o2, o3 = _outputs(fits), _outputs(fits)
+    assert _call(lib.pnp_qeif_batch_noalloc_f32, uv2, own2, 18, o2, None) == 0, lib.pnp_last_error()
+    # a batch of this size has one lane per problem: on the static device array that is the kernel
+    # whose lanes read their own rows ...
+    assert _lib.last_launch()["kernel"] == "pnp::qeif_rows6_kernel<float>"
+    # ... and through the allocating entry point, on host memory, the LDS-staged one: same bits
+    assert _call(lib.pnp_qeif_batch_f32, uv2, own2, 18, o3, _lib.PTR_HOST, None) == 0, lib.pnp_last_error()
+    assert _lib.last_launch()["kernel"] == "pnp::qeif_kernel<1, 6, float, false>"
+    for k in o2:
+        assert np.array_equal(o2[k], o3[k], equal_nan=True), k
+    ref = c_oracle.qeif_batch(uv6.astype(np.float64), P6f.astype(np.float64), K)
+    reps = fits // len(uv6)
+    assert np.array_equal(o2["iters"][:reps * len(uv6)], np.tile(ref["iters"], reps))
+    assert np.abs(o2["R"][:len(uv6)].reshape(-1, 3, 3) - ref["R"]).max() <= 5e-7
