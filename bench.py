@@ -596,7 +596,7 @@ def main():
                 ms_per_call_results_reused=round(hs_reused * 1e3, 3),
                 solves_per_s_results_reused=round(B / hs_reused, 1),
                 host_lane_threads=lib.pnp_host_lane_threads(local_rank),
-                what="NumPy arrays in, NumPy arrays out: chunks through page-locked buffers on the library's 8 standing host threads, kernels launched on those buffers")
+                what="NumPy arrays in, NumPy arrays out: chunks through page-locked buffers on the library's standing host threads, kernels launched on those buffers")
             # ... and as host tensors in page-locked memory: the kernels work on them over the bus
             uv_p, xyz_p = torch.from_numpy(uv_h).pin_memory(), torch.from_numpy(xyz_h).pin_memory()
 

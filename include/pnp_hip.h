@@ -31,8 +31,8 @@
  *   - Host-pointer calls never copy to device memory when they can help it: the kernels are
  *     launched on host memory and read and write it over the bus.  A call all of whose arrays
  *     are page-locked, mapped host memory (hipHostMalloc and the like) is one launch on those
- *     arrays.  Otherwise calls that move 8 MB or more are cut into chunks of up to 4 MB which
- *     eight host threads per device carry through page-locked buffers and streams of the
+ *     arrays.  Otherwise calls that move 8 MB or more are cut into chunks of up to 1 MB which
+ *     twelve host threads per device carry through page-locked buffers and streams of the
  *     library's own: copy a chunk of the pageable arrays in, launch on the buffer, copy the
  *     results out, the threads overlapping each other; a side (inputs, outputs) that is
  *     page-locked is used as it is.  The threads are started by the first such call on a device
@@ -295,7 +295,7 @@ const char *pnp_last_kernel_name(void);
 void pnp_last_launch(int64_t *grid, int32_t *block, int32_t *lds_bytes);
 
 /* Number of host threads the library keeps for chunked host-pointer calls on `device`: 0 until
- * the first such call, 8 afterwards. */
+ * the first such call, 12 afterwards. */
 int pnp_host_lane_threads(int device);
 
 /* Largest N accepted by the solvers. */

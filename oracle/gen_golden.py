@@ -110,7 +110,7 @@ def main():
     ap.add_argument('--ref', default='/root/reference/scripts')
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
     ap.add_argument('--n-stress', type=int, default=10000)
-    ap.add_argument('--only', default='', help='comma-separated section numbers (1-16); default all')
+    ap.add_argument('--only', default='', help='comma-separated section numbers (1-17); default all')
     ap.add_argument('--workers', type=int, default=8, help='processes of section 15')
     args = ap.parse_args()
     out_dir = os.path.abspath(args.out)
@@ -671,6 +671,50 @@ def main():
             res.append(lm68.solve_pnp_LM_single_pattern(uv_to_dict(uv[i].astype(np.float64), keys68),
                                                         lm68.np_point_3d_pretransfer_dict_list[0]))
         save('lm12_n68.npz', seed=np.int64(51), uv=uv, xyz=P68, **pack(res))
+
+    # ---- 17. the pre-transform of the pattern (PNP_SOLVER_LIB.py:27-31, :96-98, :2988-2994), which
+    # the reference ships switched off: set on an instance, pattern store rebuilt, then the three
+    # live solvers.  Two settings: the constructor's own (R_ah = I, t_ah = (0, 0, -0.5)) and the one
+    # its comments name (R_ah = a 45 degree pitch, t_ah = 0).
+    if want(17):
+        import contextlib
+        import io
+        n = 48
+        rng = np.random.default_rng(61)
+        poses = [draw_stress_pose(rng) for _ in range(n)]
+        uv = np.zeros((n, 15, 2))
+        for i, (roll, pitch, yaw, t) in enumerate(poses):
+            R = gt.get_rotation_matrix_from_Euler(roll, yaw, pitch, is_degree=True)
+            uv[i] = dict_to_uv(gt.perspective_projection_golden_landmarks(R, t, is_quantized=True), keys15)
+        out = {}
+        for tag, R_ah, t_ah in (('a', np.eye(3), np.array([[0.0, 0.0, -0.5]]).T),
+                                ('b', gt.get_rotation_matrix_from_Euler(0.0, 0.0, 45.0, is_degree=True), np.zeros((3, 1)))):
+            with contextlib.redirect_stdout(io.StringIO()):
+                pt = PNPS.PNP_SOLVER(K, [alex], pattern_scale_list=[1.0], verbose=False)
+            pt.is_using_pre_transform = True
+            pt.pre_trans_R_a_h, pt.pre_trans_t_a_h = R_ah, t_ah
+            pt.update_the_selected_golden_pattern(0, alex, 1.0)
+            moved = pt.np_point_3d_pretransfer_dict_list[0]
+            res_q, res_d, res_l, side_R, side_t = [], [], [], [], []
+            for i in range(n):
+                img = uv_to_dict(uv[i], keys15)
+                res_q.append(pt.solve_pnp(img))
+                side_R.append(pt.np_R_c_a_est.copy())
+                side_t.append(pt.np_t_c_a_est[:, 0].copy())
+                with np.errstate(all='ignore'):
+                    res_d.append(pt.solve_pnp_single_pattern(img, moved))
+                    res_l.append(pt.solve_pnp_LM_single_pattern(img, moved))
+            R0 = gt.get_rotation_matrix_from_Euler(10.0, -20.0, 5.0, is_degree=True)
+            t0 = np.array([[0.05], [-0.02], [0.9]])
+            proj = pt.perspective_projection_golden_landmarks(R0, t0, is_quantized=False, is_pretrans_points=True)
+            out.update({tag + '_R_ah': R_ah, tag + '_t_ah': t_ah[:, 0],
+                        tag + '_moved': np.array([moved[k][:, 0] for k in keys15]),
+                        tag + '_proj_moved': dict_to_uv(proj, keys15),
+                        tag + '_side_R': np.array(side_R), tag + '_side_t': np.array(side_t)})
+            for name, res in (('qeif', res_q), ('dlt', res_d), ('lm12', res_l)):
+                out.update({'%s_%s_%s' % (tag, name, k): v for k, v in pack(res).items()})
+        save('pre_transform.npz', seed=np.int64(61), uv15=uv, keys15=np.array(keys15), lm6=np.array(LM6),
+             proj_R=R0, proj_t=t0[:, 0], **out)
 
     print('done in %.0f s; numpy %s' % (time.time() - t_start, np.__version__))
 

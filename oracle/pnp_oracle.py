@@ -354,13 +354,17 @@ def dlt_block_reconstruction(phi, se_force=0):
     return R, t, t3, k2, similarity
 
 
-def dlt_solve(uv, P, K=K_DEFAULT, num_it=3, se_override=None):
+def dlt_solve(uv, P, K=K_DEFAULT, num_it=3, se_override=None, rcond=None):
     """Iterated linear DLT (:205-430): `num_it` rounds of  Delta_i = theta_i.phi3 + 1
     (clamped, :3031-3046), A (2N,8) with x/y rows interleaved (:3048-3092), phi = pinv(A) B
     (:293), block reconstruction (:366), phi3 <- R[2,:]/t3 (:4002-4017), and the residual of
     the reconstructed pose (:372-380).  The closing reconstruction (:403) repeats the last
     in-loop one exactly (it does not read phi3), so it is not recomputed.  se_override: one
-    forced mirror sign (+1 / -1, 0 = as computed) per round, see dlt_block_reconstruction."""
+    forced mirror sign (+1 / -1, 0 = as computed) per round, see dlt_block_reconstruction.
+    rcond: None is the reference's call, numpy.linalg.pinv with its default cut-off (1e-15 of the
+    largest singular value); a number replaces that cut-off, for tests that look at what a
+    solver with a coarser notion of rank returns.  The result also carries the smallest ratio of
+    singular values of A over the rounds (sv_ratio)."""
     P = np.asarray(P, dtype=np.float64)
     n = P.shape[0]
     Bx, By = normalized_xy(uv, K)
@@ -370,6 +374,7 @@ def dlt_solve(uv, P, K=K_DEFAULT, num_it=3, se_override=None):
     min_abs_k2 = np.inf
     min_abs_sim = np.inf
     min_abs_delta = np.inf
+    sv_ratio = np.inf
     for rnd in range(num_it):
         Delta = P @ phi3 + 1.0
         eps = 10 ** -7
@@ -381,7 +386,9 @@ def dlt_solve(uv, P, K=K_DEFAULT, num_it=3, se_override=None):
         A[0::2, 6] = 1.0 / Delta
         A[1::2, 3:6] = P / Delta[:, None]
         A[1::2, 7] = 1.0 / Delta                                       # :3057-3061
-        phi = np.linalg.pinv(A) @ B                                    # :293
+        phi = (np.linalg.pinv(A) if rcond is None else np.linalg.pinv(A, rcond=rcond)) @ B   # :293
+        sv = np.linalg.svd(A, compute_uv=False)
+        sv_ratio = min(sv_ratio, sv[-1] / sv[0]) if np.isfinite(sv).all() and sv[0] > 0 else sv_ratio
         R, t, t3, k2, sim = dlt_block_reconstruction(phi, se_override[rnd] if se_override else 0)
         min_abs_k2 = min(min_abs_k2, abs(k2))
         min_abs_sim = min(min_abs_sim, abs(sim))
@@ -391,7 +398,7 @@ def dlt_solve(uv, P, K=K_DEFAULT, num_it=3, se_override=None):
     roll, yaw, pitch = R_to_euler(R, is_degree=True)
     return dict(R=R, t=t, t3=t3, roll=roll, yaw=yaw, pitch=pitch, res_norm=res_norm,
                 iters=num_it, min_abs_k2=min_abs_k2, min_abs_sim=min_abs_sim,
-                min_abs_delta=min_abs_delta)
+                min_abs_delta=min_abs_delta, sv_ratio=sv_ratio)
 
 
 # ---------------------------------------------------------------------------

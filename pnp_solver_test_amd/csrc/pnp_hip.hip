@@ -130,14 +130,20 @@ constexpr int64_t kMomentMinBatch = 2048;
 // chunk by chunk.  They end when the library is unloaded or the process exits.
 // Measured on the pool's hosts: one thread copies pageable -> page-locked memory at 23 GB/s, eight
 // at 80 GB/s; page-locked memory crosses the bus at 57 GB/s in either direction, both at once.
+// Lanes and chunk size from a sweep on one box (1M six-point problems with a pattern each, C ABI
+// with existing result arrays, best of 12 calls): 8 lanes x 4 MB 3.0 ms, 8 x 2 MB 2.86, 8 x 1 MB
+// 2.58, 8 x 512 KB 2.94, 12 x 1 MB 2.57-2.58 (and the steadier median), 12 x 512 KB 2.82, 16 x 512 KB
+// 2.89: small chunks shorten the fill and drain of the pipeline until the per-chunk launch and
+// synchronisation cost takes over; the extra lanes help most when the result arrays are fresh
+// pages that the copies out have to fault in.
 #ifndef PNP_PIPE_LANES
-#define PNP_PIPE_LANES 8
+#define PNP_PIPE_LANES 12
 #endif
-#ifndef PNP_PIPE_CHUNK_MB
-#define PNP_PIPE_CHUNK_MB 4
+#ifndef PNP_PIPE_CHUNK_KB
+#define PNP_PIPE_CHUNK_KB 1024
 #endif
 constexpr int kPipeLanes = PNP_PIPE_LANES;
-constexpr size_t kPipeChunkBytes = size_t(PNP_PIPE_CHUNK_MB) << 20;   // input bytes per chunk, about
+constexpr size_t kPipeChunkBytes = size_t(PNP_PIPE_CHUNK_KB) << 10;   // input bytes per chunk, about
 #ifndef PNP_PIPE_MIN_MB
 #define PNP_PIPE_MIN_MB 8
 #endif

@@ -749,6 +749,90 @@ def test_dropin_homogeneous_component_is_honoured(golden, torch_dev):
     assert abs(res - ref["res_norm"]) <= 1e-9 * max(1.0, ref["res_norm"])
 
 
+def test_dropin_landmark_noise_driver_sequence(golden, torch_dev):
+    """The call sequence of the landmark-noise driver, through the class and its dicts as the
+    driver makes it (/root/reference/scripts/LM_noise_test.py:262-312): rotation from Euler angles,
+    pattern 0 selected, the golden landmarks projected with the bounding-box quantisation step and
+    returned as plain (u, v), a deep copy polluted in place by the seed-42 noise, stacked back to
+    homogeneous vectors, solve_pnp.  Held to the reference's own run of the reduced grid
+    (3 yaw x 3 sigma x 200 draws): the clean pixels bit for bit, every yaw estimate to 2e-3 degrees
+    (the reference run rounded its polluted pixels to float32 first, which moves them by 1e-5 px)."""
+    import copy
+    g = golden("lm_noise_small")
+    gt = pnp.PNP_SOLVER(K, [copy.deepcopy(po.PATTERN_ALEXANDER)], pattern_scale_list=[1.0], verbose=False)
+    est = pnp.PNP_SOLVER(K, [po.PATTERN_ALEXANDER], pattern_scale_list=[1.0], verbose=False)
+
+    def to_global(value, local=112, glob=30):                      # LM_noise_test.py:187-189
+        return value / float(local) * float(glob)
+
+    q = to_global(1.0)
+    assert q == float(g["quantize_q"])
+    noise = g["noise"]
+    worst = 0.0
+    for yi, yaw_i in enumerate(g["yaw_list"]):
+        R_gt = gt.get_rotation_matrix_from_Euler(0.0, yaw_i, 0.0, is_degree=True)
+        t_gt = np.array([0.0, 0.0, 1.0]).reshape((3, 1))
+        gt.set_golden_pattern_id(0)
+        lm = gt.perspective_projection_golden_landmarks(R_gt, t_gt, is_quantized=True, quantize_q=q,
+                                                        is_pretrans_points=False, is_returning_homogeneous_vec=False)
+        assert list(lm) == list(po.PATTERN_ALEXANDER) and all(v.shape == (2,) for v in lm.values())
+        assert np.array_equal(np.array([lm[k] for k in lm]), g["uv_clean"][yi])
+        for si, sigma in enumerate(g["sigma_list"]):
+            s_glob = to_global(sigma)
+            for ni in range(noise.shape[0]):
+                polluted = copy.deepcopy(lm)
+                noise_i = s_glob * noise[ni, :, :]
+                for idx, k in enumerate(polluted):
+                    polluted[k] += noise_i[idx, :].reshape((2,))
+                img = {k: np.vstack((polluted[k].reshape((2, 1)), 1.0)) for k in polluted}
+                R, t, t3, roll, yaw, pitch, res = est.solve_pnp(img)
+                worst = max(worst, abs(yaw - g["yaw_est"][yi, si, ni]))
+        assert all(np.array_equal(lm[k], g["uv_clean"][yi][i]) for i, k in enumerate(lm))    # the clean dict was not touched
+    assert worst <= 2e-3, worst
+
+
+def test_dropin_pre_transform(golden, torch_dev):
+    """is_using_pre_transform set on an instance (the reference ships it switched off,
+    /root/reference/scripts/PNP_SOLVER_LIB.py:27; the pattern store applies it at :96-98 and every
+    solver composes the estimate with it, :2988-2994, :410-416, :2739-2745): solve_pnp and the two
+    named solvers against the reference's own runs with the same flag, for the constructor's
+    setting and for the one its comments name, with the side effects np_R_c_a_est / np_t_c_a_est
+    (the estimate BEFORE the composition)."""
+    g = golden("pre_transform")
+    keys15 = [str(k) for k in g["keys15"]]
+    for tag in ("a", "b"):
+        s = pnp.PNP_SOLVER(K, [po.PATTERN_ALEXANDER], pattern_scale_list=[1.0])
+        s.is_using_pre_transform = True
+        s.pre_trans_R_a_h, s.pre_trans_t_a_h = g[tag + "_R_ah"], g[tag + "_t_ah"].reshape(3, 1)
+        s.update_the_selected_golden_pattern(0, po.PATTERN_ALEXANDER, 1.0)
+        moved = s.np_point_3d_pretransfer_dict_list[0]
+        for i in range(len(g["uv15"])):
+            img = img_dict(g["uv15"][i], keys15)
+            R, t, t3, roll, yaw, pitch, res = s.solve_pnp(img)
+            assert np.abs(R - g[tag + "_qeif_R"][i]).max() <= 1e-9 and np.abs(t[:, 0] - g[tag + "_qeif_t"][i]).max() <= 1e-9
+            assert t3 == t[2, 0] and abs(t3 - g[tag + "_qeif_t3"][i]) <= 1e-9
+            assert max(abs(roll - g[tag + "_qeif_roll"][i]), abs(yaw - g[tag + "_qeif_yaw"][i]),
+                       abs(pitch - g[tag + "_qeif_pitch"][i])) <= 1e-6
+            assert abs(res - g[tag + "_qeif_res_norm"][i]) <= 1e-10
+            assert np.abs(s.np_R_c_a_est - g[tag + "_side_R"][i]).max() <= 1e-9
+            assert np.abs(s.np_t_c_a_est[:, 0] - g[tag + "_side_t"][i]).max() <= 1e-9
+            assert np.abs(s.np_R_c_a_est - R).max() > 1e-3 or tag == "a"          # setting b rotates the estimate
+            assert np.abs(s.np_t_c_a_est - t).max() > 1e-3 or tag == "b"          # setting a shifts it
+            # the LM solver on the reference's own dtype equals it wherever it converged (it is
+            # chaotic elsewhere); the DLT where the branch margins of its reconstruction allow
+            Rl, tl, *_ = s.solve_pnp_LM_single_pattern(img, moved)
+            if g[tag + "_lm12_res_norm"][i] < 1e-2 and np.isfinite(g[tag + "_lm12_R"][i]).all():
+                assert np.abs(Rl - g[tag + "_lm12_R"][i]).max() <= 1e-6
+        refd = c_oracle.dlt_batch(g["uv15"], g[tag + "_moved"], K)
+        cmp_ok = 0
+        for i in range(len(g["uv15"])):
+            Rd, td, *_ = s.solve_pnp_single_pattern(img_dict(g["uv15"][i], keys15), moved)
+            if refd["margins"][i].min() > 1e-7 and np.isfinite(g[tag + "_dlt_R"][i]).all():
+                assert np.abs(Rd - g[tag + "_dlt_R"][i]).max() <= 1e-7, (tag, i)
+                cmp_ok += 1
+        assert cmp_ok >= 40
+
+
 def test_dropin_named_solvers(golden, torch_dev):
     s = pnp.PNP_SOLVER(K, [po.PATTERN_ALEXANDER])
     pat = s.np_point_3d_pretransfer_dict_list[0]
@@ -1469,6 +1553,7 @@ def test_row_reading_kernels_equal_the_staged_kernels(golden, torch_dev, tmp_pat
         "import pnp_solver_test_amd as pnp\n"
         "from pnp_solver_test_amd import _lib, synth\n"
         "lib = _lib.load(); d = np.load(%r); out = {}; kernels = []; K = _lib.k_array(synth.K_DEFAULT)\n"
+        "lib.pnp_set_lanes_per_problem(1)\n"          # as for a large batch: batches of this size would get 4 lanes per problem and the staged kernels either way
         "st = torch.cuda.current_stream().cuda_stream\n"
         "def run(tag, m, uv, xyz, stride):\n"
         "    B, sfx, dt = uv.shape[0], ('f32' if uv.dtype == torch.float32 else 'f64'), uv.dtype\n"
@@ -1507,7 +1592,12 @@ def test_row_reading_kernels_equal_the_staged_kernels(golden, torch_dev, tmp_pat
         if k != "kernels":
             assert np.array_equal(outs["rows"][k], outs["staged"][k], equal_nan=True), k
     # ... and the row-reading results are the solver's, not two equal failures
-    ref = solve_dev(uv[:B], P6f, torch_dev)
+    lib = _lib.load()
+    lib.pnp_set_lanes_per_problem(1)
+    try:
+        ref = solve_dev(uv[:B], P6f, torch_dev)
+    finally:
+        lib.pnp_set_lanes_per_problem(0)
     assert np.array_equal(outs["rows"]["f32_own_qeif_R"].reshape(B, 3, 3), ref["R"])
     assert np.array_equal(outs["rows"]["f32_wide_qeif_t"], ref["t"])
     assert np.isfinite(outs["rows"]["f64_planar_dlt_R"]).all()

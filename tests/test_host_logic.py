@@ -188,6 +188,28 @@ def test_constructor_semantics():
     assert s.np_point_3d_dict_list[0]["eye_l_96"][0, 0] == 0.016
 
 
+def test_pre_transform_pattern_store_matches_reference(golden):
+    """The pre-transform switched on as one would on the reference object (attribute set, pattern
+    store rebuilt through update_the_selected_golden_pattern): the moved pattern and its projection
+    (is_pretrans_points=True) equal the reference's bit for bit, the plain pattern stays as it was."""
+    g = golden("pre_transform")
+    keys15 = [str(k) for k in g["keys15"]]
+    for tag in ("a", "b"):
+        s = make_solver()
+        plain_before = {k: v.copy() for k, v in s.np_point_3d_dict_list[0].items()}
+        assert all(np.array_equal(s.np_point_3d_pretransfer_dict_list[0][k], plain_before[k]) for k in keys15)
+        s.is_using_pre_transform = True
+        s.pre_trans_R_a_h, s.pre_trans_t_a_h = g[tag + "_R_ah"], g[tag + "_t_ah"].reshape(3, 1)
+        assert s.update_the_selected_golden_pattern(0, po.PATTERN_ALEXANDER, 1.0) is True
+        moved = s.np_point_3d_pretransfer_dict_list[0]
+        assert list(moved) == keys15 and all(moved[k].shape == (3, 1) for k in keys15)
+        assert np.array_equal(np.array([moved[k][:, 0] for k in keys15]), g[tag + "_moved"])
+        assert all(np.array_equal(s.np_point_3d_dict_list[0][k], plain_before[k]) for k in keys15)
+        proj = s.perspective_projection_golden_landmarks(g["proj_R"], g["proj_t"].reshape(3, 1), is_quantized=False,
+                                                         is_pretrans_points=True)
+        assert np.array_equal(np.array([proj[k][0:2, 0] for k in keys15]), g[tag + "_proj_moved"])
+
+
 def test_missing_landmark_raises_keyerror_before_any_device_work():
     s = make_solver()
     img = {k: np.array([[1.0], [2.0], [1.0]]) for k in po.LM6_KEYS[:-1]}
