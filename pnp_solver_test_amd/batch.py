@@ -84,7 +84,7 @@ def solve_pnp_batch(uv, xyz, K, *, method="qeif", params=None, num_it=None, want
              60 MB of NumPy results for a million problems costs about a millisecond of page
              faults).  ValueError if an array is missing or does not fit.
 
-    Returns a dict: R (B,3,3), t (B,3), t3 (B,), res_norm (B,), rpy_deg (B,3) = roll, yaw, pitch
+    Returns a dict: R (B,3,3), t (B,3), t3 (B,) (a view of t[:, 2]), res_norm (B,), rpy_deg (B,3) = roll, yaw, pitch
     in the reference's tuple order (if want_rpy), iters (B,) int32 (QEIF only).  Arrays are of
     the same kind as `uv`: NumPy, torch on the same device, or - for a host tensor in pinned
     memory - pinned host tensors (no copies then: the kernels work on that memory over the bus; a
@@ -145,11 +145,14 @@ def _solve_numpy(lib, uv, xyz, Kc, method, params, num_it, want_rpy, patterns, f
     _call(lib, method, ptr(uv), ptr(src), stride, n_pat, Kc, B, N, params, num_it, ptr(out["R"]),
           ptr(out["t"]), ptr(out.get("res_norm")), ptr(iters), ptr(rpy), ptr(pid), _lib.PTR_HOST, None,
           patterns is not None, ft)
-    if reuse is not None and isinstance(reuse.get("t3"), np.ndarray) and reuse["t3"].shape == (B,) and reuse["t3"].dtype == ft:
-        out["t3"] = reuse["t3"]
-        np.copyto(out["t3"], out["t"][:, 2])
-    else:
-        out["t3"] = out["t"][:, 2].copy()
+    # t3 is a view of t, as on the torch path (a strided copy of a million values costs 0.4 ms);
+    # a reused result dict keeps the view object it already holds
+    t3 = out["t"][:, 2]
+    held = None if reuse is None else reuse.get("t3")
+    if (isinstance(held, np.ndarray) and held.shape == t3.shape and held.strides == t3.strides
+            and held.__array_interface__["data"][0] == t3.__array_interface__["data"][0]):
+        t3 = held
+    out["t3"] = t3
     if rpy is not None:
         out["rpy_deg"] = rpy
     if iters is not None:

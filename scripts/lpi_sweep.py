@@ -40,8 +40,9 @@ B68 = 1 << 18
 P68 = synth.face68()
 uv68 = torch.from_numpy(synth.stress_batch(B68, seed=46, pattern=P68, chunk=1 << 15)[0]).to(dev)
 P68d = torch.from_numpy(P68.astype(np.float32)).to(dev)
+own68 = P68d[None].expand(B68, 68, 3).contiguous()
 sweep = {"qeif_n6_b1m_per_problem_xyz": {}, "qeif_n6_b1m_shared": {}, "dlt_n6_b1m_per_problem_xyz": {},
-         "qeif_n68_b256k_shared": {}}
+         "qeif_n68_b256k_shared_point_form": {}, "qeif_n68_b256k_per_problem_xyz_point_form": {}}
 for lanes in (1, 2, 4, 8, 16, 32, 64):
     lib.pnp_set_lanes_per_problem(lanes)
     nb = B if lanes <= 8 else B >> 3          # keep the slow mappings short; rates are per problem
@@ -49,8 +50,14 @@ for lanes in (1, 2, 4, 8, 16, 32, 64):
     sweep["qeif_n6_b1m_shared"][lanes] = nb / kernel_ms(lambda: pnp.solve_pnp_batch(uv[:nb], P6, K, want_rpy=False)) * 1e3
     sweep["dlt_n6_b1m_per_problem_xyz"][lanes] = nb / kernel_ms(lambda: pnp.solve_pnp_batch(uv[:nb], xyz[:nb], K, method="dlt", want_rpy=False)) * 1e3
     nb68 = B68 if lanes <= 16 else B68 >> 2
-    eff = lib.pnp_get_lanes_per_problem(nb68, 68, 0)
-    sweep["qeif_n68_b256k_shared"]["%d(ran %d)" % (lanes, eff)] = nb68 / kernel_ms(lambda: pnp.solve_pnp_batch(uv68[:nb68], P68d, K, want_rpy=False)) * 1e3
+    # a forced lane count may take up to 160 KB of LDS per workgroup: what ran is read back
+    for key, pat, stride in (("qeif_n68_b256k_shared_point_form", P68d, 0),
+                             ("qeif_n68_b256k_per_problem_xyz_point_form", own68, 204)):
+        x = pat if stride == 0 else pat[:nb68]
+        rate = nb68 / kernel_ms(lambda: pnp.solve_pnp_batch(uv68[:nb68], x, K, want_rpy=False)) * 1e3
+        ran = _lib.last_launch()
+        sweep[key]["asked %d" % lanes] = dict(solves_per_s=rate, ran_lanes=lib.pnp_get_lanes_per_problem(nb68, 68, stride),
+                                              kernel=ran["kernel"], lds_bytes=ran["lds_bytes"])
 lib.pnp_set_lanes_per_problem(0)
 out["solves_per_s_by_lanes_per_problem"] = sweep
 
