@@ -7,6 +7,6 @@ for lib in "" "$@"; do
     echo "== lib=${lib:-in-tree}"
     PNP_HIP_LIB=${lib:+$PWD/$lib} timeout -k 10 150 python3 -u scripts/moment_phases.py 2>&1 | grep "own max_it" || exit 1
 done
-echo "== in-tree, equal chunks"
-PNP_MOMENT_PLAIN=1 timeout -k 10 150 python3 -u scripts/moment_phases.py 2>&1 | grep "own max_it" || exit 1
+echo "== in-tree A/B build, equal chunks"
+PNP_HIP_LIB=$PWD/pnp_solver_test_amd/libpnp_hip_ab.so PNP_MOMENT_PLAIN=1 timeout -k 10 150 python3 -u scripts/moment_phases.py 2>&1 | grep "own max_it" || exit 1
 done
