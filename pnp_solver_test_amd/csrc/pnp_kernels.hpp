@@ -460,16 +460,27 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment
             // folded by the compiler into read-then-use within one trip).  The trip has no
             // branch: behind a condition the second point's reads are sunk to where they are
             // used and waited for on the spot; an odd last point is taken after the loop.
-            Staged pa, pb;
-            fetch(c0, 0, pa);
+            if constexpr (SHARED) {
+                Staged pa, pb;
+                fetch(c0, 0, pa);
 #pragma unroll 1
-            for (int i = 0; i + 1 < cn; i += 2) {
-                fetch(c0, i + 1, pb);
-                accumulate(pa);
-                fetch(c0, min(i + 2, cn - 1), pa);
-                accumulate(pb);
+                for (int i = 0; i + 1 < cn; i += 2) {
+                    fetch(c0, i + 1, pb);
+                    accumulate(pa);
+                    fetch(c0, min(i + 2, cn - 1), pa);
+                    accumulate(pb);
+                }
+                if (cn & 1) accumulate(pa);
+            } else {
+                // with a pattern per problem the landing registers of the pattern leave no room for
+                // a second point in flight: one point per trip (two spilled 51 registers)
+#pragma unroll 1
+                for (int i = 0; i < cn; ++i) {
+                    Staged pa;
+                    fetch(c0, i, pa);
+                    accumulate(pa);
+                }
             }
-            if (cn & 1) accumulate(pa);
         }
     }
     if (tid >= nprob) return;  // no barrier follows
@@ -516,9 +527,11 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment
     extern __shared__ __align__(16) unsigned char lds_raw[];
     piece_t *s_uv = reinterpret_cast<piece_t *>(lds_raw);
     piece_t *s_xyz = s_uv + LU * BLOCK;
-    // column swizzles: a quarter-wavefront's staging write covers 2 rows times 8 pixel pieces, or one
-    // row times 12 pattern pieces, which the piece index spreads over the 16 slots of an LDS row
-    auto swz_u = [](int q) { return (q << 1) & 15; };
+    // column swizzles: LDS writes meet their banks eight lanes at a time (128 bytes), and eight
+    // neighbouring staging lanes hold the eight pixel pieces of one row, or eight of the twelve
+    // pattern pieces of one row: the piece index spreads them over the eight 16-byte slots
+    // (counted: a quarter of the bank conflicts of a two-rows-by-eight-pieces spread)
+    auto swz_u = [](int q) { return q & 15; };
     auto swz_x = [](int q) { return q & 15; };
     const int tid = threadIdx.x;
     const int64_t first = static_cast<int64_t>(blockIdx.x) * BLOCK;
@@ -544,34 +557,93 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment
 
     const int ku = tid % LU, ju = tid / LU, kx = tid % LX, jx = tid / LX;
     const int p0_u = first_len(ju), p0_x = first_len(jx), p0_me = first_len(tid);
+    // A pattern run is 192 bytes, a line and a half: where a chunk ends inside a 128-byte line of
+    // the pattern array, that line would be asked for twice, by this chunk and by the next, a chunk
+    // period apart - and a CU's LDS turns over more bytes per period than its share of L2 holds, so
+    // the second request goes to memory again (counted: 1.28 times the input).  Instead the chunk
+    // that meets the line first takes all of it: the pieces that belong to the head of the next
+    // chunk (up to four, the rest of the line) are loaded by the four lanes of the run that have
+    // no piece of their own (kx = 12..15), stay in their landing registers, and are written to LDS
+    // with the next chunk, whose first lanes then have nothing to load.  Runs advance by 192 bytes,
+    // so a chunk that hands pieces on never receives any: one landing set serves.  Only whole
+    // pieces are handed on (rows and chunk starts at multiples of 16 bytes, the common case);
+    // otherwise the chunk ends where it did before.
+    const unsigned x_align = static_cast<unsigned>(reinterpret_cast<uintptr_t>(xyz_blk)) & 127u;
+    auto run_x = [&](int t, int &start, int &len) {
+        start = chunk_start(p0_x, t);
+        len = max(0, min(N, p0_x + C * t) - start);
+    };
+    auto handed_on = [&](int t) {   // pieces of chunk t + 1 that chunk t loads, for this thread's rows
+        if (t < 0 || t + 1 >= chunks || (row_x & 1u)) return 0;   // (rows 16 apart share their place in a line only at even strides)
+        int sx, lx, sn, ln;
+        run_x(t, sx, lx);
+        run_x(t + 1, sn, ln);
+        if (lx <= 0 || ln <= 0) return 0;
+        const unsigned end = x_align + (static_cast<unsigned>(jx) * row_x + 3u * static_cast<unsigned>(sx + lx)) * static_cast<unsigned>(sizeof(T));
+        const unsigned rest = (128u - (end & 127u)) & 127u;   // bytes from the end of the run to the end of its line
+        return (rest != 0u && rest <= 64u && (rest & 15u) == 0u && (end & 15u) == 0u) ? static_cast<int>(rest >> 4) : 0;
+    };
     piece_t pre_uv[RU], pre_xyz[RX];
-    auto prefetch = [&](int t) {
+    // The loads of one chunk, as offsets that advance by a fixed stride from one row pass to the next.
+    struct Plan {
+        unsigned vu, du, vx, dx;
+        bool take_x;   // false: a spare lane with nothing to take keeps what it holds
+    };
+    auto plan = [&](int t) {
         // a piece that lies wholly past its row's chunk is given an offset no descriptor covers:
         // it returns zeros without a memory access
         // (the whole offset goes in the per-lane operand: the range check does not see the scalar one)
         const int su = chunk_start(p0_u, t), lu = min(N, p0_u + C * t) - su;
-        const int sx = chunk_start(p0_x, t), lx = min(N, p0_x + C * t) - sx;
+        int sx, lx;
+        run_x(t, sx, lx);
+        const int got = handed_on(t - 1), give = handed_on(t);
         constexpr unsigned kNowhere = 0xfffffff0u;
-        const bool live_u = EP * ku < 2 * lu, live_x = kx < LXA && EP * kx < 3 * lx;
-        unsigned vu = live_u ? ((static_cast<unsigned>(ju) * row_u + 2u * su) + EP * ku) * static_cast<unsigned>(sizeof(T)) : kNowhere;
-        unsigned vx = live_x ? ((static_cast<unsigned>(jx) * row_x + 3u * sx) + EP * kx) * static_cast<unsigned>(sizeof(T)) : kNowhere;
-        const unsigned du = live_u ? stride_u : 0u, dx = live_x ? stride_x : 0u;
-#pragma unroll
-        for (int r = 0; r < RU; ++r, vu += du) pre_uv[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, vu, 0, 0);
-#pragma unroll
-        for (int r = 0; r < RX; ++r, vx += dx) pre_xyz[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, vx, 0, 0);
+        const bool live_u = EP * ku < 2 * lu;
+        Plan pl;
+        pl.vu = live_u ? ((static_cast<unsigned>(ju) * row_u + 2u * su) + EP * ku) * static_cast<unsigned>(sizeof(T)) : kNowhere;
+        pl.du = live_u ? stride_u : 0u;
+        // own pieces: kx in [got, 12) within the run; pieces handed on: kx - 12 in [0, give), from the
+        // head of the next run.  The four spare lanes keep what they hold when they have nothing to take.
+        const bool own = kx < LXA;
+        const int piece = own ? kx : kx - LXA;
+        const bool live_x = own ? (kx >= got && EP * kx < 3 * lx) : (piece < give);
+        const unsigned run0 = static_cast<unsigned>(jx) * row_x + 3u * static_cast<unsigned>(own ? sx : sx + lx);
+        pl.vx = live_x ? (run0 + EP * piece) * static_cast<unsigned>(sizeof(T)) : kNowhere;
+        pl.dx = live_x ? stride_x : 0u;
+        pl.take_x = own || give > 0;
+        return pl;
     };
-    auto commit = [&]() {
+    // Row passes [RU part / parts, RU (part + 1) / parts) of the pixel loads and the same share of the pattern loads.
+    auto issue = [&](Plan &pl, int part, int parts) {
+#pragma unroll
+        for (int r = 0; r < RU; ++r)
+            if (r * parts / RU == part) {
+                pre_uv[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, pl.vu, 0, 0);
+                pl.vu += pl.du;
+            }
+        if (pl.take_x) {
+#pragma unroll
+            for (int r = 0; r < RX; ++r)
+                if (r * parts / RX == part) {
+                    pre_xyz[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, pl.vx, 0, 0);
+                    pl.vx += pl.dx;
+                }
+        }
+    };
+    auto commit = [&](int t) {
         // The columns are formed at each write (one exclusive-or): as values that stay the same
         // from chunk to chunk they would be kept in registers, and spilled.  The empty statement
         // makes the two swizzles look redefined in every pass.
-        int su = swz_u(ku), sx = swz_x(kx);
+        const int got = handed_on(t - 1);
+        const bool own = kx < LXA;
+        const int piece = own ? kx : kx - LXA;          // the spare lanes write what was handed on: pieces 0 .. got - 1
+        int su = swz_u(ku), sx = swz_x(piece);
         asm volatile("" : "+v"(su), "+v"(sx));
 #pragma unroll
         for (int r = 0; r < RU; ++r) s_uv[ku * BLOCK + ((ju + r * JU) ^ su)] = pre_uv[r];
-        if (kx < LXA) {
+        if (own ? kx >= got : piece < got) {
 #pragma unroll
-            for (int r = 0; r < RX; ++r) s_xyz[kx * BLOCK + ((jx + r * JX) ^ sx)] = pre_xyz[r];
+            for (int r = 0; r < RX; ++r) s_xyz[piece * BLOCK + ((jx + r * JX) ^ sx)] = pre_xyz[r];
         }
     };
     Moments M;
@@ -601,20 +673,35 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment
             }
         }
     };
-    prefetch(0);
+#pragma unroll
+    for (int r = 0; r < RX; ++r) pre_xyz[r] = piece_t{0u, 0u, 0u, 0u};   // the spare lanes' set is written by loads only
+    {
+        Plan pl = plan(0);
+        issue(pl, 0, 1);
+    }
+    // The loads of the next chunk are issued a share at a time between the trips that consume this
+    // one: a wavefront that issues 24 loads in a row stands at the memory pipeline for as long as
+    // the whole consume step takes (measured: 45 % of the pass), and does its arithmetic only
+    // afterwards; in turns, the arithmetic runs while the pipeline takes the loads in.
+    constexpr int TRIPS = C / EP;
+    static_assert(RU % TRIPS == 0 && RX % TRIPS == 0, "the loads divide among the trips");
     for (int t = 0; t < chunks; ++t) {
         __syncthreads();  // the previous chunk has been consumed
-        commit();
+        commit(t);
         __syncthreads();
-        if (t + 1 < chunks) prefetch(t + 1);
-        const int start = chunk_start(p0_me, t), cn = max(0, min(N, p0_me + C * t) - start);
-        if (tid < nprob) {
-#pragma unroll 1
-            for (int i = 0; i < cn; i += EP) {
+        const bool more = t + 1 < chunks;
+        Plan pl = plan(more ? t + 1 : t);
+        const int start = chunk_start(p0_me, t), cn = (tid < nprob) ? max(0, min(N, p0_me + C * t) - start) : 0;
+#pragma unroll
+        for (int trip = 0; trip < TRIPS; ++trip) {
+            if (more) issue(pl, trip, TRIPS);
+            __builtin_amdgcn_sched_barrier(0);
+            if (EP * trip < cn) {
                 Trip f;
-                fetch(i / EP, f);
-                accumulate(f, cn - i);
+                fetch(trip, f);
+                accumulate(f, cn - EP * trip);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (tid >= nprob) return;  // no barrier follows

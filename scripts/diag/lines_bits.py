@@ -22,7 +22,7 @@ from pnp_solver_test_amd import _lib, synth  # noqa: E402
 _lib.load().pnp_set_qeif_form(_lib.QEIF_FORM_MOMENTS)
 rng = np.random.default_rng(11)
 out, kernels = {}, []
-for N, B in ((32, 1500), (68, 1100), (68, 4099), (130, 700), (24, 513)):
+for N, B in ((32, 1500), (68, 1100), (68, 4099), (130, 700), (24, 513), (33, 900), (69, 777), (512, 300)):
     P = rng.uniform([-0.07, -0.05, -0.04], [0.07, 0.12, 0.02], (N, 3))
     uv, _ = synth.stress_batch(B, seed=N, pattern=P, K=synth.K_DEFAULT, is_quantized=True)
     own = np.ascontiguousarray(np.broadcast_to(P.astype(np.float32), (B, N, 3)))

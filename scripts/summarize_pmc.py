@@ -2,9 +2,13 @@
 """Condenses the rocprofv3 --pmc passes of scripts/gpu_pmc.sh (gpurun_out/pmc/*) into
 profiles/<tag>_pmc_summary.json and the per-launch HBM traffic that bench.py reports.
 
-HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (both in KiB): on gfx950 FETCH_SIZE counts
-each 128-byte request of a wide coalesced read as 64 bytes, WRITE_SIZE is exact for streaming
-stores.  The factor is checked here against the known input size of each launch."""
+HBM bytes per launch = read bytes + WRITE_SIZE.  Read bytes come from the read requests counted by
+size (TCC_EA0_RDREQ_32B / _64B / _128B, pass "rdreq"): 32 n32 + 64 n64 + 128 n128.  FETCH_SIZE, the
+derived counter, tallies a 128-byte request as 64 bytes on gfx950 (its expression takes the
+128-byte share from TCC_BUBBLE, which stays 0), so where the rdreq pass is missing the older rule
+stands in: 2 * FETCH_SIZE for wide coalesced reads, a calibrated factor for the moment kernels'
+narrower runs.  WRITE_SIZE is exact for streaming stores.  Both are checked here against the known
+input size of each launch."""
 import collections
 import csv
 import glob
@@ -55,7 +59,7 @@ def per_launch(name):
 
 
 summary = {}
-for p in ("fetch", "write", "sq1", "sq2", "grbm"):
+for p in ("fetch", "rdreq", "write", "sq1", "sq2", "grbm"):
     for label, vals in per_launch(p).items():
         summary.setdefault(label, {}).update({k: v for k, v in vals.items() if k != "dur_ns"})
         summary[label].setdefault("profiled_kernel_us", {})[p] = round(vals["dur_ns"] / 1e3, 1)
@@ -111,6 +115,13 @@ for label, kern, B, N, own in LAUNCHES:
         s["fetch_bytes_calibrated"] = ratio * in_bytes
         s["hbm_bytes_per_launch"] = s["fetch_bytes_calibrated"] + s["write_bytes"]
         del s["fetch_bytes_2x"], s["fetch_2x_over_input"]
+    if all(k in s for k in ("TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum")):
+        n32, n64, n128 = s["TCC_EA0_RDREQ_32B_sum"], s["TCC_EA0_RDREQ_64B_sum"], s["TCC_EA0_RDREQ_128B_sum"]
+        s["read_bytes_by_request_size"] = 32 * n32 + 64 * n64 + 128 * n128
+        s["read_requests"] = dict(n32=n32, n64=n64, n128=n128, all=s.get("TCC_EA0_RDREQ_sum"))
+        s["read_bytes_by_request_size_over_input"] = round(s["read_bytes_by_request_size"] / in_bytes, 4)
+        s["hbm_bytes_per_launch_by_older_rule"] = s["hbm_bytes_per_launch"]
+        s["hbm_bytes_per_launch"] = s["read_bytes_by_request_size"] + s["write_bytes"]
     if "SQ_ACTIVE_INST_VALU" in s and "GRBM_GUI_ACTIVE" in s:
         # SQ_* activity counters tick in quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs
         s["valu_busy_frac"] = round(4 * s["SQ_ACTIVE_INST_VALU"] / 1024 / (s["GRBM_GUI_ACTIVE"] / 8), 4)
@@ -122,7 +133,8 @@ for label, kern, B, N, own in LAUNCHES:
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 json.dump(summary, open(os.path.join(ROOT, "profiles", tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
 traffic["qeif_n6_b1m_bytes_per_launch"] = traffic.get("qeif_n6_b1m_per_problem_xyz_bytes_per_launch")
-traffic["source"] = "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_*, separate passes)" % tag
+traffic["source"] = ("profiles/%s_pmc_summary.json (rocprofv3 --pmc, separate passes: read requests by size "
+                     "TCC_EA0_RDREQ_32B/_64B/_128B, WRITE_SIZE, FETCH_SIZE, SQ_*, GRBM)" % tag)
 traffic["kernels"] = dict(KERNEL_SEEN)
 import subprocess
 try:
@@ -136,4 +148,5 @@ except Exception:
     traffic["commit"] = None
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1, sort_keys=True)
 for label, s in summary.items():
-    print(label, {k: s[k] for k in ("hbm_bytes_per_launch", "fetch_2x_over_input", "read_bytes_over_input", "valu_busy_frac", "valu_insts_per_wave") if k in s})
+    print(label, {k: s[k] for k in ("hbm_bytes_per_launch", "read_bytes_by_request_size_over_input", "read_requests", "fetch_2x_over_input",
+                                    "read_bytes_over_input", "valu_busy_frac", "valu_insts_per_wave") if k in s})
