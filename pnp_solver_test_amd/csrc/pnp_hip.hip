@@ -439,7 +439,7 @@ bool lines_kernel_allowed()
     if (hipGetDevice(&dev) != hipSuccess) return false;
     const uint64_t bit = uint64_t(1) << (dev & 63);
     if (!((allowed.load() | refused.load()) & bit)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pnp::qeif_moment_lines_kernel<T>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pnp::qeif_moment_lines_kernel<T, false>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  static_cast<int>(lines_kernel_lds<T>()));
         if (e != hipSuccess) (void)hipGetLastError();
@@ -463,7 +463,16 @@ int launch_qeif_moment(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_str
         const size_t pat = static_cast<size_t>(9) * N * sizeof(double);
         const size_t lds_long = ((2 * c_shared * row * sizeof(T) + 7) & ~static_cast<size_t>(7)) + pat;
         const size_t lds_short = ((2 * c_own * row * sizeof(T) + 7) & ~static_cast<size_t>(7)) + pat;
-        if (lds_long <= kLdsPlain) {
+        // pixels in whole cache lines (16-byte pieces, 8 per problem) + the table
+        const size_t lds_lines = static_cast<size_t>(2) * pnp::kMomentChunkLine<T> * block * sizeof(T) + pat;
+        // measured on 128k-512k problems: ahead (2-3 %) from about 48 float32 (24 float64) points per
+        // problem, and it asks for every line once where the equal chunks ask for a quarter of them twice
+        const bool long_rows = static_cast<size_t>(N) * sizeof(T) >= 192;
+        if (lds_lines <= kLdsPlain && long_rows && !g_moment_plain) {
+            hipLaunchKernelGGL((pnp::qeif_moment_lines_kernel<T, true>), grid, dim3(block), lds_lines, s, uv, xyz, xyz_stride, ki,
+                               B, N, p, R, t, res, iters, rpy);
+            note_launch(nblk, block, lds_lines, "pnp::qeif_moment_lines_kernel<%s, true>", elem_name<T>());
+        } else if (lds_long <= kLdsPlain) {
             hipLaunchKernelGGL((pnp::qeif_moment_kernel<T, c_shared, true>), grid, dim3(block), lds_long, s, uv, xyz,
                                xyz_stride, ki, B, N, p, R, t, res, iters, rpy);
             note_launch(nblk, block, lds_long, "pnp::qeif_moment_kernel<%s, %d, true>", elem_name<T>(), c_shared);
@@ -481,9 +490,9 @@ int launch_qeif_moment(hipStream_t s, const T *uv, const T *xyz, int64_t xyz_str
         // measured on 256k-512k problems: ahead from about 24 float32 (12 float64) points per problem
         const bool long_rows = static_cast<size_t>(N) * sizeof(T) >= 96;
         if (lines_ready && offsets_fit && long_rows && !g_moment_plain) {
-            hipLaunchKernelGGL((pnp::qeif_moment_lines_kernel<T>), grid, dim3(block), lines_lds, s, uv, xyz, xyz_stride, ki,
+            hipLaunchKernelGGL((pnp::qeif_moment_lines_kernel<T, false>), grid, dim3(block), lines_lds, s, uv, xyz, xyz_stride, ki,
                                B, N, p, R, t, res, iters, rpy);
-            note_launch(nblk, block, lines_lds, "pnp::qeif_moment_lines_kernel<%s>", elem_name<T>());
+            note_launch(nblk, block, lines_lds, "pnp::qeif_moment_lines_kernel<%s, false>", elem_name<T>());
         } else {
             const size_t lds = 5 * c_own * row * sizeof(T);
             hipLaunchKernelGGL((pnp::qeif_moment_kernel<T, c_own, false>), grid, dim3(block), lds, s, uv, xyz,

@@ -512,7 +512,12 @@ constexpr int kMomentChunkLine = 64 / static_cast<int>(sizeof(T));
 // workgroups there is no room for padding, so the staging writes are spread over the banks by the
 // exclusive-or instead.  A lane reads its problem's pieces whole: five 16-byte reads bring EP
 // points (EP = elements of a piece), a quarter of the LDS instructions of element-wise staging.
-template <typename T>
+// SHARED (one pattern for all problems, xyz_stride == 0): only the pixels are staged this way
+// (8 pieces per problem); the pattern sits in LDS behind them as float64 [p, packed p p^T] per
+// point as in qeif_moment_kernel<T, C, true>.  Lanes whose rows start at different places in a
+// line are at different points of the pattern in the same trip: the table is read at up to C
+// addresses per instruction, 72 bytes apart, which fall into different banks.
+template <typename T, bool SHARED>
 __global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment_lines_kernel(
     const T *__restrict__ uv, const T *__restrict__ xyz, int64_t xyz_stride, KinvRows ki, int64_t B, int N,
     QeifParams p, T *__restrict__ R_out, T *__restrict__ t_out, T *__restrict__ res_out,
@@ -527,6 +532,7 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment
     extern __shared__ __align__(16) unsigned char lds_raw[];
     piece_t *s_uv = reinterpret_cast<piece_t *>(lds_raw);
     piece_t *s_xyz = s_uv + LU * BLOCK;
+    const double *s_pat = reinterpret_cast<const double *>(s_xyz);   // SHARED: the table takes the place of the pattern pieces
     // column swizzles: LDS writes meet their banks eight lanes at a time (128 bytes), and eight
     // neighbouring staging lanes hold the eight pixel pieces of one row, or eight of the twelve
     // pattern pieces of one row: the piece index spreads them over the eight 16-byte slots
@@ -545,6 +551,27 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T *>(xyz_blk), 0,
         static_cast<int>((static_cast<unsigned>(nprob - 1) * row_x + 3u * static_cast<unsigned>(N)) * sizeof(T)), 0x00020000);
+    Moments M;
+    moments_clear(M);
+    if constexpr (SHARED) {
+        double *table = reinterpret_cast<double *>(s_xyz);
+        for (int i = tid; i < N; i += BLOCK) {
+            const double X = static_cast<double>(xyz[3 * i]), Y = static_cast<double>(xyz[3 * i + 1]);
+            const double Z = static_cast<double>(xyz[3 * i + 2]);
+            double *d = table + 9 * i;
+            d[0] = X; d[1] = Y; d[2] = Z;
+            d[3] = X * X; d[4] = Y * X; d[5] = Y * Y; d[6] = Z * X; d[7] = Z * Y; d[8] = Z * Z;
+        }
+        __syncthreads();
+        double part[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int i = tid & 63; i < N; i += 64)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) part[k] += s_pat[9 * i + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) M.m0[k] = wave_uniform(group_sum<64>(part[k]));
+#pragma unroll
+        for (int k = 0; k < 6; ++k) M.S0[k] = wave_uniform(group_sum<64>(part[3 + k]));
+    }
 
     // where row j starts within its line, in points: (u0 + N j) mod C
     const int u0 = static_cast<int>((reinterpret_cast<uintptr_t>(uv) / (2 * sizeof(T)) + static_cast<uint64_t>(first) * N) &
@@ -574,7 +601,7 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment
         len = max(0, min(N, p0_x + C * t) - start);
     };
     auto handed_on = [&](int t) {   // pieces of chunk t + 1 that chunk t loads, for this thread's rows
-        if (t < 0 || t + 1 >= chunks || (row_x & 1u)) return 0;   // (rows 16 apart share their place in a line only at even strides)
+        if (SHARED || t < 0 || t + 1 >= chunks || (row_x & 1u)) return 0;   // (rows 16 apart share their place in a line only at even strides)
         int sx, lx, sn, ln;
         run_x(t, sx, lx);
         run_x(t + 1, sn, ln);
@@ -583,7 +610,7 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment
         const unsigned rest = (128u - (end & 127u)) & 127u;   // bytes from the end of the run to the end of its line
         return (rest != 0u && rest <= 64u && (rest & 15u) == 0u && (end & 15u) == 0u) ? static_cast<int>(rest >> 4) : 0;
     };
-    piece_t pre_uv[RU], pre_xyz[RX];
+    piece_t pre_uv[RU], pre_xyz[SHARED ? 1 : RX];
     // The loads of one chunk, as offsets that advance by a fixed stride from one row pass to the next.
     struct Plan {
         unsigned vu, du, vx, dx;
@@ -602,6 +629,11 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment
         Plan pl;
         pl.vu = live_u ? ((static_cast<unsigned>(ju) * row_u + 2u * su) + EP * ku) * static_cast<unsigned>(sizeof(T)) : kNowhere;
         pl.du = live_u ? stride_u : 0u;
+        if constexpr (SHARED) {
+            pl.vx = pl.dx = 0u;
+            pl.take_x = false;
+            return pl;
+        }
         // own pieces: kx in [got, 12) within the run; pieces handed on: kx - 12 in [0, give), from the
         // head of the next run.  The four spare lanes keep what they hold when they have nothing to take.
         const bool own = kx < LXA;
@@ -621,13 +653,15 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment
                 pre_uv[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, pl.vu, 0, 0);
                 pl.vu += pl.du;
             }
-        if (pl.take_x) {
+        if constexpr (!SHARED) {
+            if (pl.take_x) {
 #pragma unroll
-            for (int r = 0; r < RX; ++r)
-                if (r * parts / RX == part) {
-                    pre_xyz[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, pl.vx, 0, 0);
-                    pl.vx += pl.dx;
-                }
+                for (int r = 0; r < RX; ++r)
+                    if (r * parts / RX == part) {
+                        pre_xyz[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, pl.vx, 0, 0);
+                        pl.vx += pl.dx;
+                    }
+            }
         }
     };
     auto commit = [&](int t) {
@@ -641,13 +675,13 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment
         asm volatile("" : "+v"(su), "+v"(sx));
 #pragma unroll
         for (int r = 0; r < RU; ++r) s_uv[ku * BLOCK + ((ju + r * JU) ^ su)] = pre_uv[r];
-        if (own ? kx >= got : piece < got) {
+        if constexpr (!SHARED) {
+            if (own ? kx >= got : piece < got) {
 #pragma unroll
-            for (int r = 0; r < RX; ++r) s_xyz[piece * BLOCK + ((jx + r * JX) ^ sx)] = pre_xyz[r];
+                for (int r = 0; r < RX; ++r) s_xyz[piece * BLOCK + ((jx + r * JX) ^ sx)] = pre_xyz[r];
+            }
         }
     };
-    Moments M;
-    moments_clear(M);
     // EP points are two pieces of pixels and three of pattern.
     struct Trip {
         piece_t raw[5];
@@ -655,26 +689,35 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment
     auto fetch = [&](int trip, Trip &f) {
         f.raw[0] = s_uv[(2 * trip) * BLOCK + (tid ^ swz_u(2 * trip))];
         f.raw[1] = s_uv[(2 * trip + 1) * BLOCK + (tid ^ swz_u(2 * trip + 1))];
+        if constexpr (!SHARED) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) f.raw[2 + q] = s_xyz[(3 * trip + q) * BLOCK + (tid ^ swz_x(3 * trip + q))];
+            for (int q = 0; q < 3; ++q) f.raw[2 + q] = s_xyz[(3 * trip + q) * BLOCK + (tid ^ swz_x(3 * trip + q))];
+        }
     };
-    auto accumulate = [&](const Trip &f, int left) {
+    // `point`: index within the row of the trip's first point (SHARED: where to read the table)
+    auto accumulate = [&](const Trip &f, int left, int point) {
         T e_uv[2 * EP], e_xyz[3 * EP];
         __builtin_memcpy(e_uv, &f.raw[0], 32);
-        __builtin_memcpy(e_xyz, &f.raw[2], 48);
+        if constexpr (!SHARED) __builtin_memcpy(e_xyz, &f.raw[2], 48);
 #pragma unroll
         for (int q = 0; q < EP; ++q) {
             if (q < left) {
                 const double u = static_cast<double>(e_uv[2 * q]), v = static_cast<double>(e_uv[2 * q + 1]);
                 const double bx = __builtin_fma(ki.a00, u, __builtin_fma(ki.a01, v, ki.a02));
                 const double by = __builtin_fma(ki.a10, u, __builtin_fma(ki.a11, v, ki.a12));
-                moments_add(M, static_cast<double>(e_xyz[3 * q]), static_cast<double>(e_xyz[3 * q + 1]),
-                            static_cast<double>(e_xyz[3 * q + 2]), bx, by);
+                if constexpr (SHARED) {
+                    const double *d = s_pat + 9 * (point + q);
+                    const double pt[3] = {d[0], d[1], d[2]}, pp[6] = {d[3], d[4], d[5], d[6], d[7], d[8]};
+                    moments_add_axes(M, pp, pt, bx, by);
+                } else {
+                    moments_add(M, static_cast<double>(e_xyz[3 * q]), static_cast<double>(e_xyz[3 * q + 1]),
+                                static_cast<double>(e_xyz[3 * q + 2]), bx, by);
+                }
             }
         }
     };
 #pragma unroll
-    for (int r = 0; r < RX; ++r) pre_xyz[r] = piece_t{0u, 0u, 0u, 0u};   // the spare lanes' set is written by loads only
+    for (int r = 0; r < (SHARED ? 1 : RX); ++r) pre_xyz[r] = piece_t{0u, 0u, 0u, 0u};   // the spare lanes' set is written by loads only
     {
         Plan pl = plan(0);
         issue(pl, 0, 1);
@@ -699,7 +742,7 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment
             if (EP * trip < cn) {
                 Trip f;
                 fetch(trip, f);
-                accumulate(f, cn - EP * trip);
+                accumulate(f, cn - EP * trip, start + EP * trip);
             }
             __builtin_amdgcn_sched_barrier(0);
         }

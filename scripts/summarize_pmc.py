@@ -5,10 +5,9 @@ profiles/<tag>_pmc_summary.json and the per-launch HBM traffic that bench.py rep
 HBM bytes per launch = read bytes + WRITE_SIZE.  Read bytes come from the read requests counted by
 size (TCC_EA0_RDREQ_32B / _64B / _128B, pass "rdreq"): 32 n32 + 64 n64 + 128 n128.  FETCH_SIZE, the
 derived counter, tallies a 128-byte request as 64 bytes on gfx950 (its expression takes the
-128-byte share from TCC_BUBBLE, which stays 0), so where the rdreq pass is missing the older rule
-stands in: 2 * FETCH_SIZE for wide coalesced reads, a calibrated factor for the moment kernels'
-narrower runs.  WRITE_SIZE is exact for streaming stores.  Both are checked here against the known
-input size of each launch."""
+128-byte share from TCC_BUBBLE, which stays 0), so where the rdreq pass is missing 2 * FETCH_SIZE
+stands in (right for kernels that ask for whole lines only).  WRITE_SIZE is exact for streaming
+stores.  Both are checked here against the known input size of each launch."""
 import collections
 import csv
 import glob
@@ -24,8 +23,8 @@ src = os.path.join(ROOT, "gpurun_out", "pmc")
 LAUNCHES = [("qeif_n6_b1m_per_problem_xyz", "qeif_rows6_kernel<", 1 << 20, 6, True),
             ("dlt_n6_b1m_per_problem_xyz", "dlt_rows6_kernel<", 1 << 20, 6, True),
             ("qeif_n6_b1m_shared_pattern", "qeif_rows6_kernel<", 1 << 20, 6, False),
-            ("qeif_n68_b256k_shared_pattern", "qeif_moment_kernel<float, 16, true>", 1 << 18, 68, False),
-            ("qeif_n68_b256k_per_problem_xyz", "qeif_moment_lines_kernel<float>", 1 << 18, 68, True)]
+            ("qeif_n68_b256k_shared_pattern", "qeif_moment_lines_kernel<float, true>", 1 << 18, 68, False),
+            ("qeif_n68_b256k_per_problem_xyz", "qeif_moment_lines_kernel<float, false>", 1 << 18, 68, True)]
 
 
 KERNEL_SEEN = {}   # label -> kernel name the counter rows carry (without "void" and the argument list)
@@ -75,52 +74,16 @@ for label, kern, B, N, own in LAUNCHES:
     s["write_bytes"] = s["WRITE_SIZE"] * 1024
     s["hbm_bytes_per_launch"] = s["fetch_bytes_2x"] + s["write_bytes"]
     s["fetch_2x_over_input"] = round(s["fetch_bytes_2x"] / in_bytes, 4)
-    if "qeif_moment_kernel" in kern:
-        # The moment kernel reads 4 bytes per lane in runs of 2C pixel floats / 3C pattern floats per
-        # problem row; FETCH_SIZE counts such reads neither at 1/2 (the 16-bytes-per-lane rule) nor
-        # at 1.  scripts/probes/fetch_calibration.hip reads a known byte count once in each of
-        # these shapes (N = 68 rows): FETCH_SIZE bytes / true bytes = 0.7696 for 64-byte runs
-        # (pixels, C = 8), 0.9288 for 128-byte runs (pixels, C = 16), 1.1093 for 96-byte runs
-        # (pattern, C = 8).  Divided out, what is left is the kernel's re-read ratio.
-        C = 8 if own else 16
-        uv_b, xyz_b = B * 8 * N, (B * 12 * N if own else 0)
-        counted_if_read_once = (0.7696 if C == 8 else 0.9288) * uv_b + 1.1093 * xyz_b
-        ratio = s["FETCH_SIZE"] * 1024 / counted_if_read_once
-        s["fetch_calibration"] = ("FETCH_SIZE calibrated on this access shape (scripts/probes/fetch_calibration.hip): "
-                                  "a single read of the inputs would count %.0f bytes" % counted_if_read_once)
-        s["read_bytes_over_input"] = round(ratio, 4)
-        if ratio < 1.0:
-            # Fewer requests than the calibration loads of the same shape: those ask for most lines
-            # in two parts a chunk period apart and fetch them twice, while this kernel finds the
-            # second part in L2 (with a shared pattern a chunk period touches less than the L2
-            # holds).  FETCH_SIZE is requests x 64 bytes and a request brings 64 or 128 bytes, so
-            # the bytes lie between FETCH_SIZE and twice that; the input is read from beyond the L2
-            # at least once per launch (it is 4x the L2s), so the input size is what is reported.
-            s["read_bytes_bracket"] = [round(s["FETCH_SIZE"] * 1024), round(2 * s["FETCH_SIZE"] * 1024)]
-            s["fetch_calibration"] += "; calibrated ratio %.4f < 1: see read_bytes_bracket, reported as the input read once" % ratio
-            ratio = 1.0
-        s["fetch_bytes_calibrated"] = ratio * in_bytes
-        s["hbm_bytes_per_launch"] = s["fetch_bytes_calibrated"] + s["write_bytes"]
-        del s["fetch_bytes_2x"], s["fetch_2x_over_input"]
-    if "qeif_moment_lines_kernel" in kern:
-        # 16-byte pieces: pixel runs are whole 128-byte lines (counted at half, like any wide read),
-        # pattern runs are 192 bytes at multiples of 64 bytes, i.e. one 128-byte and one 64-byte request,
-        # and short requests are counted at more than half.  scripts/probes/fetch_calibration.hip
-        # (calib_lines) reads uv and xyz once in exactly this shape: FETCH_SIZE bytes / true bytes
-        # = 0.6312.  Divided out, what is left is the kernel's re-read ratio.
-        ratio = s["FETCH_SIZE"] * 1024 / (0.6312 * in_bytes)
-        s["fetch_calibration"] = ("FETCH_SIZE calibrated on this access shape (scripts/probes/fetch_calibration.hip, "
-                                  "calib_lines): a single read of the inputs would count %.0f bytes" % (0.6312 * in_bytes))
-        s["read_bytes_over_input"] = round(ratio, 4)
-        s["fetch_bytes_calibrated"] = ratio * in_bytes
-        s["hbm_bytes_per_launch"] = s["fetch_bytes_calibrated"] + s["write_bytes"]
-        del s["fetch_bytes_2x"], s["fetch_2x_over_input"]
+    # FETCH_SIZE tallies a 128-byte request as 64 bytes (hence the factor 2) and a 64-byte one as
+    # 64: where short requests occur it over-counts, and it was once "calibrated" on probes of the
+    # kernels' access shapes, which shared the kernels' re-reads and hid them.  The request counts
+    # by size below are what the traffic figure is made of; 2 x FETCH_SIZE stays beside it.
     if all(k in s for k in ("TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum")):
         n32, n64, n128 = s["TCC_EA0_RDREQ_32B_sum"], s["TCC_EA0_RDREQ_64B_sum"], s["TCC_EA0_RDREQ_128B_sum"]
         s["read_bytes_by_request_size"] = 32 * n32 + 64 * n64 + 128 * n128
         s["read_requests"] = dict(n32=n32, n64=n64, n128=n128, all=s.get("TCC_EA0_RDREQ_sum"))
         s["read_bytes_by_request_size_over_input"] = round(s["read_bytes_by_request_size"] / in_bytes, 4)
-        s["hbm_bytes_per_launch_by_older_rule"] = s["hbm_bytes_per_launch"]
+        s["hbm_bytes_per_launch_by_2x_fetch_size"] = s["hbm_bytes_per_launch"]
         s["hbm_bytes_per_launch"] = s["read_bytes_by_request_size"] + s["write_bytes"]
     if "SQ_ACTIVE_INST_VALU" in s and "GRBM_GUI_ACTIVE" in s:
         # SQ_* activity counters tick in quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs
