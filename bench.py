@@ -642,6 +642,10 @@ def main():
             os._exit(0)
 
         gather = {}
+        if rank == 0:
+            # should a rank die inside a collective (no exception, no time-out to catch), what was
+            # measured is at least in the log; standard output still carries one line only
+            print("bench.py: headline before the optional exchange: " + json.dumps(line), file=sys.stderr, flush=True)
         watchdog = threading.Timer(GATHER_DEADLINE_S, bail)
         watchdog.daemon = True
         watchdog.start()
