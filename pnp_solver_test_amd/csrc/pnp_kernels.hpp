@@ -524,6 +524,9 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment
     int32_t *__restrict__ iters_out, T *__restrict__ rpy_out)
 {
     constexpr int BLOCK = kMomentBlock<T>, C = kMomentChunkLine<T>;
+#ifdef PNP_STAMP_WG   // debug builds only: start, end of the accumulation pass and end of every workgroup
+    const uint64_t stamp0 = wall_clock64();   // (100 MHz), left where its first problem's rotation goes
+#endif
     constexpr int EP = 16 / static_cast<int>(sizeof(T));             // elements of a piece = points of a trip
     constexpr int LU = 2 * C / EP, JU = BLOCK / LU, RU = BLOCK / JU;  // lanes of a pixel run, rows per pass, passes
     constexpr int LXA = 3 * C / EP, LX = 16, JX = BLOCK / LX, RX = BLOCK / JX;
@@ -748,7 +751,19 @@ __global__ __launch_bounds__(kMomentBlock<T>, PNP_MOMENT_WAVES) void qeif_moment
         }
     }
     if (tid >= nprob) return;  // no barrier follows
+#ifdef PNP_STAMP_WG
+    const uint64_t stamp1 = wall_clock64();
+#endif
     moment_iterations(M, uv, xyz, xyz_stride, ki, first + tid, N, p, R_out, t_out, res_out, iters_out, rpy_out);
+#ifdef PNP_STAMP_WG
+    if (tid == 0) {
+        uint64_t *w = reinterpret_cast<uint64_t *>(R_out + first * 9);
+        w[0] = stamp0; w[1] = stamp1; w[2] = wall_clock64();
+        // where it ran: HW_ID (register 4, 32 bits) and XCC_ID (register 20, low 4 bits)
+        w[3] = (static_cast<uint64_t>(__builtin_amdgcn_s_getreg((3 << 11) | 20)) << 32) |
+               static_cast<uint32_t>(__builtin_amdgcn_s_getreg((31 << 11) | 4));
+    }
+#endif
 }
 
 template <int LPI, int NCT, typename T>
